@@ -1,0 +1,126 @@
+/*
+ * qcd_oracle.h -- CPU restatement of the QCDGPU sequential SU(N) path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the checker the HIP kernels are compared
+ * against; nothing in the product library may include, link or call it.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose arithmetic it restates.  Parity status: PINNED -- the restatement is
+ * checked against the compiled reference (oracle/_ref/qcdgpu_cpu, built from
+ * the reference's own sources by oracle/Makefile) through the fixtures under
+ * tests/golden/, in the sequential-stream ("seq") and deterministic ("gid")
+ * modes.  The Polyakov loop has no runnable reference (its only CPU twin needs
+ * an OpenCL device at run time): that one function is "parity unpinned" and is
+ * checked by closed forms only.
+ */
+#ifndef QCD_ORACLE_H
+#define QCD_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } qo_cplx;
+
+/* SU(N)/suncpp/su3/algebra_su3.h: full 3x3 complex matrix, rows u, v, w */
+typedef struct { qo_cplx u1, u2, u3, v1, v2, v3, w1, w2, w3; } qo_su3;
+/* SU(N)/suncpp/su2/algebra_su2.h: full 2x2 complex matrix, rows u, v */
+typedef struct { qo_cplx u1, u2, v1, v2; } qo_su2;
+
+/* RANLUX, SU(N)/random/random.cpp:504-574 */
+typedef struct {
+    float seeds[24];
+    int   i24, j24, in24;
+    float carry;
+    int   nskip;
+} qo_ranlux;
+
+enum { QO_RNG_SEQ = 0, QO_RNG_GID = 1, QO_RNG_PERSITE = 2 };
+
+typedef struct {
+    int group;            /* 2 or 3 */
+    int nd;               /* 4 */
+    int L[4];             /* Nx, Ny, Nz, Nt */
+    int sites;
+    int nhit;
+    double beta;
+    int ints;             /* 0 hot (unusable on the CPU path), 1 cold, 2 gid */
+    int rng_mode;         /* QO_RNG_* */
+    int nskip;            /* luxury skip: 24/48/97/223/389 */
+    unsigned randseries;
+    void *links;          /* qo_su3[nd*sites] or qo_su2[nd*sites], index gid*nd+dir */
+    qo_ranlux seq;        /* the one sequential stream */
+    qo_ranlux *streams;   /* sites/2 streams in QO_RNG_PERSITE mode */
+    unsigned long long rng_draws; /* numbers consumed (all modes but gid) */
+} qo_lattice;
+
+/* glibc rand() restated (TYPE_3 additive feedback), so that seeds do not depend on the libc */
+typedef struct { int32_t r[34]; int idx; uint32_t ring[31]; int f, b; } qo_glibc_rand;
+void     qo_srand(qo_glibc_rand *g, unsigned seed);
+int      qo_rand(qo_glibc_rand *g);
+
+void  qo_ranlux_init(qo_ranlux *r, int jseed, int nskip);
+float qo_ranlux_next(qo_ranlux *r);
+int   qo_nskip_for_level(int level);          /* RANLUX0..4 -> 24,48,97,223,389 */
+int   qo_stream_jseed(unsigned randseries, int stream); /* (stream+1)-th rand() after srand */
+
+/* index maps, SU(N)/suncpp/coord_work/coord_work.cpp */
+void     qo_gid_to_coords(const int L[4], unsigned gid, int c[4]);
+unsigned qo_coords_to_gid(const int L[4], const int c[4]);
+int      qo_neighbour(const int L[4], int gid, int dir);
+int      qo_neighbour_back(const int L[4], int gid, int dir);
+unsigned qo_odd_gid(const int L[4], unsigned i);
+unsigned qo_even_gid(const int L[4], unsigned i);
+
+/* algebra */
+qo_su3 qo_mul3(const qo_su3 *a, const qo_su3 *b);
+qo_su3 qo_herm3(const qo_su3 *a);
+void   qo_gram_schmidt3(qo_su3 *a);
+void   qo_matrix_gid3(qo_su3 *a, int gid, int dir, int sites);
+qo_su2 qo_mul2(const qo_su2 *a, const qo_su2 *b);
+qo_su2 qo_herm2(const qo_su2 *a);
+void   qo_matrix_gid2(qo_su2 *a, int gid, int dir, int sites);
+
+/* lattice life cycle */
+qo_lattice *qo_create(int group, const int L[4], double beta, int nhit, int ints,
+                      int rng_mode, int lux_level, unsigned randseries);
+void qo_destroy(qo_lattice *lat);
+void qo_init_links(qo_lattice *lat);
+
+/* update, SU(N)/suncpp/Update/sun_update.h */
+void qo_staple3(const qo_lattice *lat, int gid, int dir, qo_su3 *out);
+void qo_staple2(const qo_lattice *lat, int gid, int dir, qo_su2 *out);
+void qo_update_pass(qo_lattice *lat, int parity /*0 even, 1 odd*/, int dir);
+void qo_sweep(qo_lattice *lat);   /* odd X,Y,Z,T then even X,Y,Z,T */
+
+/* one link update with an explicit random source (unit tests) */
+void qo_update_link3(qo_su3 *U, const qo_su3 *stap, double beta_eff, int nhit, int gid,
+                     int gid_start, int fsites, qo_ranlux *rng, unsigned long long *draws);
+void qo_update_link2(qo_su2 *a, const qo_su2 *stap, double beta_eff, int nhit, int gid,
+                     int gid_start, int fsites, int final, qo_ranlux *rng,
+                     unsigned long long *draws);
+
+/* measurements: out[0]=spat, out[1]=temp, out[2]=total */
+void qo_plaquette(const qo_lattice *lat, double out[3]);
+void qo_action(const qo_lattice *lat, double out[3]);
+/* out = Re P, Im P, |P|^2, |P|^4 averages; "parity unpinned" */
+void qo_polyakov(const qo_lattice *lat, double out[4]);
+
+/* statistics, SU(N)/suncpp/Measurements/analysis_cpp.cpp:81-93 */
+void qo_estimates(const double *data, int n, double *mean, double *variance);
+
+/* whole run, SU(N)/suncpp/suncpp.h:73-165: fills plq[3*iter], act[3*iter] */
+void qo_simulate(qo_lattice *lat, int nav, int iter, int niter, double *plq, double *act);
+
+/* link table in the reference's device layout (double precision):
+ * SU(3): 12 rows of double4, row = quad*4+dir; SU(2): 4 rows, row = dir
+ * (SU(N)/suncl/su3_matrix_memory.cl:42-176, su2_matrix_memory.cl:55-142) */
+void qo_export_device_layout(const qo_lattice *lat, double *table, int rowsize);
+void qo_import_device_layout(qo_lattice *lat, const double *table, int rowsize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""ctypes binding of the CPU checker (oracle/libqcd_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+RNG_SEQ, RNG_GID, RNG_PERSITE = 0, 1, 2
+
+
+def _load():
+    so = os.path.join(ORACLE_DIR, "libqcd_oracle.so")
+    src = os.path.join(ORACLE_DIR, "qcd_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", ORACLE_DIR, "libqcd_oracle.so", "qcd_oracle_cli"], check=True,
+                       stdout=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    I, D, U, P = C.c_int, C.c_double, C.c_uint, C.c_void_p
+    pd = C.POINTER(C.c_double)
+    pi = C.POINTER(C.c_int)
+    lib.qo_create.restype = P
+    lib.qo_create.argtypes = [I, pi, D, I, I, I, I, U]
+    lib.qo_destroy.argtypes = [P]
+    lib.qo_init_links.argtypes = [P]
+    lib.qo_sweep.argtypes = [P]
+    lib.qo_update_pass.argtypes = [P, I, I]
+    lib.qo_plaquette.argtypes = [P, pd]
+    lib.qo_action.argtypes = [P, pd]
+    lib.qo_polyakov.argtypes = [P, pd]
+    lib.qo_simulate.argtypes = [P, I, I, I, pd, pd]
+    lib.qo_estimates.argtypes = [pd, I, pd, pd]
+    lib.qo_export_device_layout.argtypes = [P, pd, I]
+    lib.qo_import_device_layout.argtypes = [P, pd, I]
+    lib.qo_stream_jseed.restype = I
+    lib.qo_stream_jseed.argtypes = [U, I]
+    lib.qo_odd_gid.restype = U
+    lib.qo_odd_gid.argtypes = [pi, U]
+    lib.qo_even_gid.restype = U
+    lib.qo_even_gid.argtypes = [pi, U]
+    lib.qo_neighbour.restype = I
+    lib.qo_neighbour.argtypes = [pi, I, I]
+    lib.qo_neighbour_back.restype = I
+    lib.qo_neighbour_back.argtypes = [pi, I, I]
+    return lib
+
+
+lib = _load()
+
+
+class RanluxState(C.Structure):
+    _fields_ = [("seeds", C.c_float * 24), ("i24", C.c_int), ("j24", C.c_int),
+                ("in24", C.c_int), ("carry", C.c_float), ("nskip", C.c_int)]
+
+
+lib.qo_ranlux_init.argtypes = [C.POINTER(RanluxState), C.c_int, C.c_int]
+lib.qo_ranlux_next.restype = C.c_float
+lib.qo_ranlux_next.argtypes = [C.POINTER(RanluxState)]
+
+
+class GlibcRand(C.Structure):
+    _fields_ = [("r", C.c_int32 * 34), ("idx", C.c_int), ("ring", C.c_uint32 * 31),
+                ("f", C.c_int), ("b", C.c_int)]
+
+
+lib.qo_srand.argtypes = [C.POINTER(GlibcRand), C.c_uint]
+lib.qo_rand.restype = C.c_int
+lib.qo_rand.argtypes = [C.POINTER(GlibcRand)]
+
+
+def _L(L):
+    return (C.c_int * 4)(*L)
+
+
+class Lattice:
+    """One oracle lattice (links AoS [gid*nd+dir], full matrices)."""
+
+    def __init__(self, group, L, beta, nhit=10, ints=1, rng_mode=RNG_SEQ, lux=3, seed=54):
+        self.group, self.L = group, tuple(L)
+        self.sites = int(np.prod(L))
+        self.h = lib.qo_create(group, _L(L), beta, nhit, ints, rng_mode, lux, seed)
+        lib.qo_init_links(self.h)
+
+    def close(self):
+        if self.h:
+            lib.qo_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sweep(self, n=1):
+        for _ in range(n):
+            lib.qo_sweep(self.h)
+
+    def update(self, parity, direction):
+        lib.qo_update_pass(self.h, parity, direction)
+
+    def plaquette(self):
+        out = (C.c_double * 3)()
+        lib.qo_plaquette(self.h, out)
+        return np.array(out[:])
+
+    def action(self):
+        out = (C.c_double * 3)()
+        lib.qo_action(self.h, out)
+        return np.array(out[:])
+
+    def polyakov(self):
+        out = (C.c_double * 4)()
+        lib.qo_polyakov(self.h, out)
+        return np.array(out[:])
+
+    def rows(self):
+        return 12 if self.group == 3 else 4
+
+    def export_table(self, rowsize=None):
+        rowsize = rowsize or self.sites
+        t = np.zeros((self.rows(), rowsize, 4), dtype=np.float64)
+        lib.qo_export_device_layout(self.h, t.ctypes.data_as(C.POINTER(C.c_double)), rowsize)
+        return t
+
+    def import_table(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        lib.qo_import_device_layout(self.h, t.ctypes.data_as(C.POINTER(C.c_double)), t.shape[1])
+
+
+def simulate(group, L, beta, nhit, ints, rng_mode, lux, seed, nav, iter_, niter):
+    h = lib.qo_create(group, _L(L), beta, nhit, ints, rng_mode, lux, seed)
+    plq = np.zeros((iter_, 3))
+    act = np.zeros((iter_, 3))
+    lib.qo_simulate(h, nav, iter_, niter, plq.ctypes.data_as(C.POINTER(C.c_double)),
+                    act.ctypes.data_as(C.POINTER(C.c_double)))
+    lib.qo_destroy(h)
+    return plq, act
+
+
+def estimates(data):
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    m, v = C.c_double(), C.c_double()
+    lib.qo_estimates(data.ctypes.data_as(C.POINTER(C.c_double)), len(data), C.byref(m), C.byref(v))
+    return m.value, v.value
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN_DIR, name)) as f:
+        return json.load(f)
+
+
+def golden_cases(prefix="ref_"):
+    return sorted(p for p in os.listdir(GOLDEN_DIR) if p.startswith(prefix) and p.endswith(".json"))
+
+
+def init_to_args(init):
+    """init.dat keys of a fixture -> (group, L, beta, nhit, ints, lux, seed, nav, iter, niter)."""
+    L = [32, 32, 32, 32]
+    for k, v in init.items():
+        if k == "LS":
+            L[0] = L[1] = L[2] = v
+        elif k == "LT":
+            L[3] = v
+        elif k in ("L1", "L2", "L3", "L4"):
+            L[int(k[1]) - 1] = v
+    lux = int(init.get("PRNG", "RANLUX3")[-1])
+    return dict(group=init["GROUP"], L=L, beta=init["BETA"], nhit=init["NHIT"], ints=init["INTS"],
+                lux=lux, seed=init["RANDSERIES"], nav=init["NAV"], iter_=init["ITER"],
+                niter=init["NITER"])
