@@ -1,0 +1,143 @@
+/*
+ * qcdgpu_amd.h -- C-ABI of the MI355X SU(N) sweep engine (libqcdgpu_amd.so).
+ *
+ * The reference has no FFI: its de-facto boundary is the pair of C++ classes
+ * model_CL::model (run API, SU(N)/suncl/suncl.h:385-399) and GPU_CL::GPU (device service,
+ * SU(N)/clinterface/clinterface.h:219-251).  Each entry point below replaces the kernel_run /
+ * buffer_map call sites of model::lattice_simulate that are cited beside it.  Plain C types
+ * only; every function returns a status (0 = QCD_OK) instead of exiting the process the way
+ * the reference's OpenCL error handler does (SU(N)/clinterface/clinterface.cpp:225-284).
+ *
+ * Threading: one context is driven by one host thread at a time.  All work of a context is
+ * enqueued on one HIP stream (its own, or the one given to qcd_set_stream); functions that
+ * return values to the host synchronise that stream, the others are asynchronous.
+ */
+#ifndef QCDGPU_AMD_H
+#define QCDGPU_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qcd_ctx qcd_ctx;
+
+enum {
+    QCD_OK = 0,
+    QCD_ERR_INVALID = 1,      /* bad argument / unsupported configuration */
+    QCD_ERR_HIP = 2,          /* a HIP runtime call failed (see qcd_last_error) */
+    QCD_ERR_NOMEM = 3,
+    QCD_ERR_UNSUPPORTED = 4,
+    QCD_ERR_STATE = 5         /* call out of order (e.g. update before init) */
+};
+
+/* start modes: model::ints, SU(N)/suncl/suncl.h:64-68 (INTS key of init.dat) */
+enum { QCD_START_HOT = 0, QCD_START_COLD = 1, QCD_START_GID = 2 };
+
+/* run parameters <-> public fields of model (SU(N)/suncl/suncl.h:88-167) and of PRNG
+ * (SU(N)/random/random.h).  L is the FULL lattice; a context owns the x-slab
+ * [x0, x0 + nx_local) of it (the reference's SubLattice, suncl.h:470-699).  A single-GPU run
+ * has x0 = 0, nx_local = L[0], halo = 0. */
+typedef struct {
+    int      group;        /* lattice_group: 2 or 3 */
+    int      nd;           /* lattice_nd: 4 */
+    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (Ny even) */
+    int      precision;    /* 2 = double (model_precision_double); others unsupported */
+    double   beta;         /* BETA */
+    int      nhit;         /* NHIT: max heat-bath trials per SU(2) subgroup */
+    int      start_mode;   /* QCD_START_* (INTS) */
+    int      lux_level;    /* RANLUX luxury level 0..4 (PRNG = RANLUX0..RANLUX4) */
+    unsigned rand_series;  /* RANDSERIES (must be non-zero: the time-based seed is the host's job) */
+    int      device;       /* HIP device ordinal (DEVICE) */
+    int      x0;           /* first global x slice owned by this context */
+    int      nx_local;     /* number of x slices owned (SubLattice::Nx); even, or the whole lattice */
+    int      halo;         /* 0: periodic in x inside the context; 1: two halo slices, filled by
+                              qcd_halo_unpack (BigLattice geometry, suncl.cpp:2131-2148) */
+} qcd_params;
+
+typedef struct {
+    unsigned long long update_launches;   /* update_{even,odd}_{X,Y,Z,T} launches */
+    double             update_ms;         /* device time of those launches (profiling on) */
+    unsigned long long measure_launches;
+    double             measure_ms;
+    unsigned long long halo_launches;
+    double             halo_ms;
+} qcd_timing;
+
+/* model::model + lattice_init + lattice_create_buffers (suncl.cpp:142-214, 672-706, 3877-3991):
+ * selects the device, allocates the link table, the RANLUX streams and the reduction buffers. */
+int  qcd_create(qcd_ctx **out, const qcd_params *params);
+void qcd_destroy(qcd_ctx *ctx);
+
+/* message of the last failing call on this thread */
+const char *qcd_last_error(void);
+
+/* use a caller-owned hipStream_t (passed as void*) for all subsequent work; NULL = own stream */
+int qcd_set_stream(qcd_ctx *ctx, void *hip_stream);
+int qcd_synchronize(qcd_ctx *ctx);
+
+/* kernel_run(sun_init_id) (suncl.cpp:5243-5252; kernels lattice_init_cold / lattice_init_gid,
+ * SU(N)/suncl/suncl.cl:163-347): cold or gid start; also resets the RANLUX streams */
+int qcd_init_lattice(qcd_ctx *ctx);
+
+/* one kernel_run(sun_update_<parity>_<dir>_id) together with the PRNG0->produce() in front of
+ * it (suncl.cpp:5359-5374): heat-bath update of all links of direction dir (0..3 = X,Y,Z,T) on
+ * the sites of one parity (0 even, 1 odd), re-unitarisation included */
+int qcd_update(qcd_ctx *ctx, int parity, int dir);
+
+/* n full sweeps in the reference order: odd X,Y,Z,T then even X,Y,Z,T (suncpp.h:133-141).
+ * Only valid for halo = 0 (a slab needs the halo exchange between passes). */
+int qcd_sweep(qcd_ctx *ctx, int n);
+
+/* kernel_run(sun_GramSchmidt_id) (suncl.cpp:5376; kernel lattice_GramSchmidt, suncl.cl:349-396) */
+int qcd_reunitarize(qcd_ctx *ctx);
+
+/* measurement + reduce kernel pairs (suncl.cpp:5425-5483):
+ *   plaquette: out = Plq_spat, Plq_temp, Plq_total (not divided by N; cold start gives N)
+ *   action:    out = S_spat, S_temp, S_total = beta * (1 - Plq / N)
+ *   polyakov:  out = <Re P>/N, <Im P>/N, <|P|^2>/N^2, <|P|^4>/N^4
+ * The *_sums variants return this context's raw sums (for slabs: add over contexts, then
+ * normalise with the FULL volume): plaquette sums = (sum_spat, sum_temp) of ReTr over the 3+3
+ * planes; polyakov sums = (sum Re P, sum Im P, sum |P|^2, sum |P|^4). */
+int qcd_measure_plaquette(qcd_ctx *ctx, double out[3]);
+int qcd_measure_action(qcd_ctx *ctx, double out[3]);
+int qcd_measure_polyakov(qcd_ctx *ctx, double out[4]);
+int qcd_measure_plaquette_sums(qcd_ctx *ctx, double sums[2]);
+int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
+
+/* buffer_map / COPY_HOST_PTR of lattice_table (suncl.cpp:5498-5504, 3877-3991): the link table
+ * of this context's slab in the REFERENCE device layout, double precision: rows of double4,
+ * element [gindex + row*rowsize], gindex = y + z*Ny + t*Ny*Nz + x_local*Ny*Nz*Nt;
+ * SU(3): 12 rows, row = quad*4 + dir, quads (Re u1,Re u2,Re u3,Re v3), (Im u1,Im u2,Im u3,Im v3),
+ * (Re v1,Re v2,Im v1,Im v2) (SU(N)/suncl/su3_matrix_memory.cl:42-176); SU(2): 4 rows, row = dir,
+ * (Re u1,Re u2,Im u1,Im u2) (su2_matrix_memory.cl:55-142).  bytes = rows*rowsize*32. */
+int qcd_upload(qcd_ctx *ctx, const void *host_table, size_t bytes, int rowsize);
+int qcd_download(qcd_ctx *ctx, void *host_table, size_t bytes, int rowsize);
+
+/* model::UpdateEdges(dir) (suncl.cpp:4005-4061), split into its two halves so that the transport
+ * between contexts (peer copy, RCCL send/recv) is the caller's.  A message carries the links of
+ * ONE direction on the sites of ONE parity of one boundary x-slice:
+ *   qcd_halo_pack  (side 0): first owned slice  -> buffer (goes to the LEFT neighbour's side 1)
+ *   qcd_halo_pack  (side 1): last owned slice   -> buffer (goes to the RIGHT neighbour's side 0)
+ *   qcd_halo_unpack(side 0): buffer -> left halo slice;  (side 1): buffer -> right halo slice
+ * dev_buf is device memory of qcd_halo_bytes() bytes. */
+size_t qcd_halo_bytes(const qcd_ctx *ctx);
+int    qcd_halo_pack(qcd_ctx *ctx, int side, int dir, int parity, void *dev_buf);
+int    qcd_halo_unpack(qcd_ctx *ctx, int side, int dir, int parity, const void *dev_buf);
+
+/* GPU_debug.profiling + print_time_detailed (clinterface.cpp:1254-1266, 1626-1667) */
+int qcd_set_profiling(qcd_ctx *ctx, int on);
+int qcd_get_timing(qcd_ctx *ctx, qcd_timing *out);
+
+/* runs n sweeps bracketed by HIP events on the context's stream; returns the elapsed device
+ * time of the whole bracket in ms and the number of update launches inside it */
+int qcd_timed_sweeps(qcd_ctx *ctx, int n, double *elapsed_ms, unsigned long long *launches);
+
+/* number of random numbers consumed so far by all RANLUX streams of this context */
+int qcd_rng_draws(qcd_ctx *ctx, unsigned long long *draws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

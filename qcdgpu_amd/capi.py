@@ -1,0 +1,220 @@
+"""ctypes binding of libqcdgpu_amd.so (the C-ABI declared in include/qcdgpu_amd.h).
+
+There is no CPU fallback: importing this module without the built library raises, and every
+entry point that needs a device reports the HIP error it got.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libqcdgpu_amd.so")
+
+START_HOT, START_COLD, START_GID = 0, 1, 2
+
+
+class QcdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("qcdgpu_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("group", C.c_int), ("nd", C.c_int), ("L", C.c_int * 4), ("precision", C.c_int),
+                ("beta", C.c_double), ("nhit", C.c_int), ("start_mode", C.c_int),
+                ("lux_level", C.c_int), ("rand_series", C.c_uint), ("device", C.c_int),
+                ("x0", C.c_int), ("nx_local", C.c_int), ("halo", C.c_int)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("update_launches", C.c_ulonglong), ("update_ms", C.c_double),
+                ("measure_launches", C.c_ulonglong), ("measure_ms", C.c_double),
+                ("halo_launches", C.c_ulonglong), ("halo_ms", C.c_double)]
+
+
+# every symbol include/qcdgpu_amd.h declares
+EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd_synchronize",
+           "qcd_init_lattice", "qcd_update", "qcd_sweep", "qcd_reunitarize",
+           "qcd_measure_plaquette", "qcd_measure_action", "qcd_measure_polyakov",
+           "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums", "qcd_upload", "qcd_download",
+           "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_set_profiling",
+           "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws"]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P, I, D = C.c_void_p, C.c_int, C.c_double
+    pd = C.POINTER(C.c_double)
+    lib.qcd_create.argtypes = [C.POINTER(P), C.POINTER(Params)]
+    lib.qcd_destroy.argtypes = [P]
+    lib.qcd_destroy.restype = None
+    lib.qcd_last_error.restype = C.c_char_p
+    lib.qcd_set_stream.argtypes = [P, P]
+    lib.qcd_synchronize.argtypes = [P]
+    lib.qcd_init_lattice.argtypes = [P]
+    lib.qcd_update.argtypes = [P, I, I]
+    lib.qcd_sweep.argtypes = [P, I]
+    lib.qcd_reunitarize.argtypes = [P]
+    for n in ("qcd_measure_plaquette", "qcd_measure_action", "qcd_measure_polyakov",
+              "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums"):
+        getattr(lib, n).argtypes = [P, pd]
+    lib.qcd_upload.argtypes = [P, P, C.c_size_t, I]
+    lib.qcd_download.argtypes = [P, P, C.c_size_t, I]
+    lib.qcd_halo_bytes.argtypes = [P]
+    lib.qcd_halo_bytes.restype = C.c_size_t
+    lib.qcd_halo_pack.argtypes = [P, I, I, I, P]
+    lib.qcd_halo_unpack.argtypes = [P, I, I, I, P]
+    lib.qcd_set_profiling.argtypes = [P, I]
+    lib.qcd_get_timing.argtypes = [P, C.POINTER(Timing)]
+    lib.qcd_timed_sweeps.argtypes = [P, I, pd, C.POINTER(C.c_ulonglong)]
+    lib.qcd_rng_draws.argtypes = [P, C.POINTER(C.c_ulonglong)]
+    # host-only helpers (no device needed)
+    lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
+    lib.qcd_host_gid_link.argtypes = [I, I, I, I, pd]
+    lib.qcd_host_gid_randoms.argtypes = [I, I, I, C.POINTER(C.c_float)]
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise QcdError(rc, lib.qcd_last_error().decode())
+
+
+class Context:
+    """One x-slab of the lattice on one device (qcd_ctx)."""
+
+    def __init__(self, group, L, beta, nhit=10, start_mode=START_COLD, lux_level=3, rand_series=54,
+                 device=0, x0=0, nx_local=None, halo=0, precision=2):
+        self.params = Params()
+        p = self.params
+        p.group, p.nd, p.precision = group, 4, precision
+        for i in range(4):
+            p.L[i] = L[i]
+        p.beta, p.nhit, p.start_mode = beta, nhit, start_mode
+        p.lux_level, p.rand_series, p.device = lux_level, rand_series, device
+        p.x0, p.nx_local, p.halo = x0, (L[0] if nx_local is None else nx_local), halo
+        self.L = tuple(L)
+        self.group = group
+        self.sites = int(np.prod(L))
+        self.local_sites = p.nx_local * L[1] * L[2] * L[3]
+        self.h = C.c_void_p()
+        _check(lib.qcd_create(C.byref(self.h), C.byref(p)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.qcd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream_handle):
+        _check(lib.qcd_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        _check(lib.qcd_synchronize(self.h))
+
+    def init_lattice(self):
+        _check(lib.qcd_init_lattice(self.h))
+
+    def update(self, parity, direction):
+        _check(lib.qcd_update(self.h, parity, direction))
+
+    def sweep(self, n=1):
+        _check(lib.qcd_sweep(self.h, n))
+
+    def reunitarize(self):
+        _check(lib.qcd_reunitarize(self.h))
+
+    def _measure(self, fn, n):
+        out = (C.c_double * n)()
+        _check(fn(self.h, out))
+        return np.array(out[:])
+
+    def plaquette(self):
+        return self._measure(lib.qcd_measure_plaquette, 3)
+
+    def action(self):
+        return self._measure(lib.qcd_measure_action, 3)
+
+    def polyakov(self):
+        return self._measure(lib.qcd_measure_polyakov, 4)
+
+    def plaquette_sums(self):
+        return self._measure(lib.qcd_measure_plaquette_sums, 2)
+
+    def polyakov_sums(self):
+        return self._measure(lib.qcd_measure_polyakov_sums, 4)
+
+    def rows(self):
+        return 12 if self.group == 3 else 4
+
+    def upload(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        assert t.ndim == 3 and t.shape[0] == self.rows() and t.shape[2] == 4
+        _check(lib.qcd_upload(self.h, t.ctypes.data_as(C.c_void_p), t.nbytes, t.shape[1]))
+
+    def download(self, rowsize=None):
+        rowsize = rowsize or self.local_sites
+        t = np.zeros((self.rows(), rowsize, 4), dtype=np.float64)
+        _check(lib.qcd_download(self.h, t.ctypes.data_as(C.c_void_p), t.nbytes, rowsize))
+        return t
+
+    def halo_bytes(self):
+        return lib.qcd_halo_bytes(self.h)
+
+    def halo_pack(self, side, direction, parity, dev_ptr):
+        _check(lib.qcd_halo_pack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
+
+    def halo_unpack(self, side, direction, parity, dev_ptr):
+        _check(lib.qcd_halo_unpack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
+
+    def set_profiling(self, on):
+        _check(lib.qcd_set_profiling(self.h, int(on)))
+
+    def timing(self):
+        t = Timing()
+        _check(lib.qcd_get_timing(self.h, C.byref(t)))
+        return t
+
+    def timed_sweeps(self, n):
+        ms = C.c_double()
+        launches = C.c_ulonglong()
+        _check(lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
+        return ms.value, launches.value
+
+    def rng_draws(self):
+        d = C.c_ulonglong()
+        _check(lib.qcd_rng_draws(self.h, C.byref(d)))
+        return d.value
+
+
+def host_ranlux_stream(rand_series, stream, lux_level, n):
+    out = (C.c_float * n)()
+    _check(lib.qcd_host_ranlux_stream(rand_series, stream, lux_level, n, out))
+    return np.array(out[:], dtype=np.float32)
+
+
+def host_gid_link(group, gid, direction, sites):
+    q = (C.c_double * 12)()
+    _check(lib.qcd_host_gid_link(group, gid, direction, sites, q))
+    return np.array(q[:])
+
+
+def host_gid_randoms(gid, nhit, sites):
+    r = (C.c_float * 6)()
+    _check(lib.qcd_host_gid_randoms(gid, nhit, sites, r))
+    return np.array(r[:], dtype=np.float32)

@@ -1,0 +1,712 @@
+// engine.hip -- C-ABI of libqcdgpu_amd.so (declared in include/qcdgpu_amd.h) over the kernels.
+//
+// A context owns one x-slab of the lattice on one device: the link table, the per-thread RANLUX
+// streams, the closed-form "gid" table when INTS = 2, and the reduction buffers.  Every entry
+// point validates its arguments against the geometry the kernels were sized for before anything
+// is launched, and reports failures as status codes.
+#include "../../include/qcdgpu_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_seed.h"
+#include "kernels.h"
+
+using namespace qcd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(QCD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+constexpr int UPD_BLOCK = 128;
+constexpr int MEAS_BLOCK = 256;
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+struct qcd_ctx {
+    qcd_params p;
+    Geom g;
+    int ncomp;
+    hipStream_t own_stream, stream;
+    double2* U;
+    size_t U_elems;
+    RlxView rv;
+    float* gidr;
+    double2* partial;
+    int npartial;
+    double* result_dev;
+    double* result_host;  // pinned
+    unsigned long long* draws_dev;
+    unsigned long long* draws_host;  // pinned
+    bool initialized;
+    bool profiling;
+    hipEvent_t ev0, ev1;
+    qcd_timing timing;
+};
+
+namespace {
+
+int set_device(const qcd_ctx* c)
+{
+    HIP_TRY(hipSetDevice(c->p.device));
+    return QCD_OK;
+}
+
+struct Timed {
+    qcd_ctx* c;
+    int kind;
+    Timed(qcd_ctx* ctx, int k) : c(ctx), kind(k)
+    {
+        if (c->profiling) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    int finish()
+    {
+        unsigned long long* n = kind == 0 ? &c->timing.update_launches
+                              : kind == 1 ? &c->timing.measure_launches : &c->timing.halo_launches;
+        double* ms = kind == 0 ? &c->timing.update_ms : kind == 1 ? &c->timing.measure_ms : &c->timing.halo_ms;
+        (*n)++;
+        HIP_TRY(hipGetLastError());
+        if (c->profiling) {
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            HIP_TRY(hipEventSynchronize(c->ev1));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+            *ms += t;
+        }
+        return QCD_OK;
+    }
+};
+
+template <int GROUP, bool GID>
+int launch_update_dir(qcd_ctx* c, int parity, int dir)
+{
+    const Geom& g = c->g;
+    const dim3 grid(cdiv(g.vh_int, UPD_BLOCK)), block(UPD_BLOCK);
+    const double beta_eff = c->p.beta / c->p.group;  // SU(N)/suncpp/Update/sun_update.h:94
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_update<GROUP, 0, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
+        case 1: hipLaunchKernelGGL((k_update<GROUP, 1, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
+        case 2: hipLaunchKernelGGL((k_update<GROUP, 2, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
+        default: hipLaunchKernelGGL((k_update<GROUP, 3, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
+    }
+    return QCD_OK;
+}
+
+int launch_update(qcd_ctx* c, int parity, int dir)
+{
+    const bool gid = (c->p.start_mode == QCD_START_GID);
+    Timed tm(c, 0);
+    if (c->p.group == 3) {
+        if (gid) launch_update_dir<3, true>(c, parity, dir);
+        else launch_update_dir<3, false>(c, parity, dir);
+    } else {
+        if (gid) launch_update_dir<2, true>(c, parity, dir);
+        else launch_update_dir<2, false>(c, parity, dir);
+    }
+    return tm.finish();
+}
+
+// closed-form pseudo-random numbers of INTS = 2 (SU(N)/suncpp/su2/update_su2.cpp:71-76, 95-98),
+// evaluated with the host's libm in the reference's precision mix: double argument, the value
+// cast to float.  gid is the GLOBAL site number, fsites the FULL volume.
+void gid_randoms(int gid, int nhit, int fsites, float out[6])
+{
+    out[0] = fabsf((float)sin((0.005 * (1.0 + nhit) + 270.0 / fsites) * gid));
+    out[1] = fabsf((float)cos((0.005 * (1.0 + nhit) + 60.0 / fsites) * gid));
+    out[2] = fabsf((float)sin((0.005 * (1.0 + nhit) - 150.0 / fsites) * gid));
+    out[3] = fabsf((float)cos((0.005 * (1.0 + nhit) - 380.0 / fsites) * gid));
+    out[4] = fabsf((float)cos((0.08 - 270.0 / fsites) * gid));
+    out[5] = fabsf((float)sin((0.08 - 60.0 / fsites) * gid));
+}
+
+// gid start, one link in the reference device layout (lattice_matrixGID,
+// SU(N)/suncpp/su3/algebra_su3.cpp:64-80 incl. its Gram-Schmidt; su2/algebra_su2.cpp:54-64)
+void gid_link(int group, int gid, int dir, int sites, double q[12])
+{
+    const double a = (dir + 1) / 1000.0;
+    if (group == 3) {
+        double u[6], v[6];
+        u[0] = sin((a + 10.0 / sites) * gid) / 2.0;  u[1] = cos((a - 10.0 / sites) * gid) / 3.0;
+        u[2] = sin((a - 18.0 / sites) * gid) / 4.0;  u[3] = cos((a + 12.0 / sites) * gid) / 4.0;
+        u[4] = sin((a - 12.0 / sites) * gid) / 3.0;  u[5] = cos((a - 15.0 / sites) * gid) / 2.0;
+        v[0] = sin((a + 15.0 / sites) * gid) / 3.0;  v[1] = cos((a - 11.0 / sites) * gid) / 4.0;
+        v[2] = sin((a - 11.0 / sites) * gid) / 3.0;  v[3] = cos((a + 16.0 / sites) * gid) / 2.0;
+        v[4] = sin((a - 16.0 / sites) * gid) / 3.0;  v[5] = cos((a - 18.0 / sites) * gid) / 2.0;
+        // Gram-Schmidt on the host, same operation order as the device/CPU twin
+        const double nu = sqrt(u[0] * u[0] + u[2] * u[2] + u[4] * u[4] + u[1] * u[1] + u[3] * u[3] + u[5] * u[5]);
+        for (int k = 0; k < 6; k++) u[k] = u[k] / nu;
+        // sp = sum_k v_k * conj(u_k)
+        double spr = 0.0, spi = 0.0;
+        {
+            double tr[3], ti[3];
+            for (int k = 0; k < 3; k++) {
+                const double vr = v[2 * k], vi = v[2 * k + 1], ur = u[2 * k], ui = -u[2 * k + 1];
+                tr[k] = vr * ur - vi * ui;
+                ti[k] = vr * ui + vi * ur;
+            }
+            spr = (tr[0] + tr[1]) + tr[2];
+            spi = (ti[0] + ti[1]) + ti[2];
+        }
+        for (int k = 0; k < 3; k++) {
+            const double ur = u[2 * k], ui = u[2 * k + 1];
+            const double pr = ur * spr - ui * spi, pi = ur * spi + ui * spr;
+            v[2 * k] = v[2 * k] - pr;
+            v[2 * k + 1] = v[2 * k + 1] - pi;
+        }
+        const double nv = sqrt(v[0] * v[0] + v[2] * v[2] + v[4] * v[4] + v[1] * v[1] + v[3] * v[3] + v[5] * v[5]);
+        for (int k = 0; k < 6; k++) v[k] = v[k] / nv;
+        // quads: (Re u1,Re u2,Re u3,Re v3), (Im u1,Im u2,Im u3,Im v3), (Re v1,Re v2,Im v1,Im v2)
+        q[0] = u[0]; q[1] = u[2]; q[2] = u[4]; q[3] = v[4];
+        q[4] = u[1]; q[5] = u[3]; q[6] = u[5]; q[7] = v[5];
+        q[8] = v[0]; q[9] = v[2]; q[10] = v[1]; q[11] = v[3];
+    } else {
+        const double u1re = sin((a + 10.0 / sites) * gid) / 2.0;
+        const double u2im = cos((a - 10.0 / sites) * gid) / 3.0;
+        const double u2re = sin((a - 18.0 / sites) * gid) / 4.0;
+        const double u1im = sqrt(1 - u1re * u1re - u2im * u2im - u2re * u2re);
+        q[0] = u1re; q[1] = u2re; q[2] = u1im; q[3] = u2im;
+    }
+}
+
+int convert_slices(qcd_ctx* c, double4* dev_table, int rowsize, int slice0, int nslices, bool to_engine)
+{
+    const int n = nslices * c->g.gslice;
+    const dim3 grid(cdiv(n, MEAS_BLOCK)), block(MEAS_BLOCK);
+    if (c->p.group == 3) {
+        if (to_engine) hipLaunchKernelGGL((k_convert<3, true, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dev_table, rowsize, slice0, nslices);
+        else hipLaunchKernelGGL((k_convert<3, false, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dev_table, rowsize, slice0, nslices);
+    } else {
+        if (to_engine) hipLaunchKernelGGL((k_convert<2, true, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dev_table, rowsize, slice0, nslices);
+        else hipLaunchKernelGGL((k_convert<2, false, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dev_table, rowsize, slice0, nslices);
+    }
+    HIP_TRY(hipGetLastError());
+    return QCD_OK;
+}
+
+// host table of `nslices` slices (global x of the first: gx0, periodic) in the reference layout
+int upload_gid_slices(qcd_ctx* c, int gx0, int slice0, int nslices)
+{
+    const Geom& g = c->g;
+    const int rows = (c->p.group == 3) ? 12 : 4;
+    const int quads = rows / 4;
+    const int n = nslices * g.gslice;
+    std::vector<double> tab((size_t)rows * n * 4);
+    for (int xl = 0; xl < nslices; xl++) {
+        const int gx = ((gx0 + xl) % c->p.L[0] + c->p.L[0]) % c->p.L[0];
+        for (int r = 0; r < g.gslice; r++) {
+            const int gid = gx * g.gslice + r;
+            const int lg = xl * g.gslice + r;
+            for (int dir = 0; dir < 4; dir++) {
+                double q[12];
+                gid_link(c->p.group, gid, dir, g.gsites, q);
+                for (int k = 0; k < quads; k++)
+                    memcpy(&tab[((size_t)(k * 4 + dir) * n + lg) * 4], &q[4 * k], 4 * sizeof(double));
+            }
+        }
+    }
+    double4* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, tab.size() * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    int rc = QCD_OK;
+    if (e != hipSuccess) rc = fail(QCD_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    if (rc == QCD_OK) rc = convert_slices(c, dev, n, slice0, nslices, true);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dev);
+    return rc;
+}
+
+int seed_streams(qcd_ctx* c)
+{
+    const Geom& g = c->g;
+    const int ns = g.vh_int;
+    const int nskip = rlx_nskip_for_level(c->p.lux_level);
+    // stream index = GLOBAL half index of the thread's site pair: results do not depend on how
+    // the lattice is cut into slabs
+    const long first = (long)c->p.x0 * g.slice_h;
+    std::vector<int> seeds = stream_seeds(c->p.rand_series, first, ns);
+    std::vector<unsigned> st((size_t)RLX_STATE_WORDS * ns);
+    for (int i = 0; i < ns; i++) {
+        RlxRegs r;
+        rlx_seed_state(seeds[(size_t)i], nskip, r);
+        for (int w = 0; w < 24; w++) st[(size_t)w * ns + i] = r.s[w];
+        st[(size_t)24 * ns + i] = r.c;
+    }
+    HIP_TRY(hipMemcpyAsync(c->rv.slot[0], st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->rv.slot[1], 0, st.size() * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->rv.ctl, 0, (size_t)ns * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->draws_dev, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->rv.q = nskip / 24;
+    c->rv.rem = nskip % 24;
+    return QCD_OK;
+}
+
+int check_ctx(const qcd_ctx* c, bool need_init)
+{
+    if (!c) return fail(QCD_ERR_INVALID, "null context");
+    if (need_init && !c->initialized) return fail(QCD_ERR_STATE, "lattice not initialised: call qcd_init_lattice or qcd_upload first");
+    return set_device(c);
+}
+
+int reduce_partials(qcd_ctx* c, int n, int nout, double* host_out)
+{
+    hipLaunchKernelGGL((k_reduce<MEAS_BLOCK>), dim3(1), dim3(MEAS_BLOCK), 0, c->stream, c->partial, n, nout, c->result_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->result_host, c->result_dev, 2 * nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2 * nout; i++) host_out[i] = c->result_host[i];
+    return QCD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* qcd_last_error(void) { return g_err.c_str(); }
+
+int qcd_create(qcd_ctx** out, const qcd_params* p)
+{
+    if (!out || !p) return fail(QCD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (p->group != 2 && p->group != 3) return fail(QCD_ERR_INVALID, "GROUP must be 2 or 3 (got %d)", p->group);
+    if (p->nd != 4) return fail(QCD_ERR_UNSUPPORTED, "ND must be 4 (got %d)", p->nd);
+    if (p->precision != 2) return fail(QCD_ERR_UNSUPPORTED, "only double precision (2) is implemented (got %d)", p->precision);
+    for (int i = 0; i < 4; i++)
+        if (p->L[i] < 2) return fail(QCD_ERR_INVALID, "lattice extent L[%d] = %d < 2", i, p->L[i]);
+    if (p->L[1] & 1) return fail(QCD_ERR_INVALID, "Ny = %d must be even (checkerboard pairs sites 2h, 2h+1)", p->L[1]);
+    if (p->nhit < 1) return fail(QCD_ERR_INVALID, "NHIT = %d < 1", p->nhit);
+    if (p->lux_level < 0 || p->lux_level > 4) return fail(QCD_ERR_INVALID, "RANLUX level %d not in 0..4", p->lux_level);
+    if (p->rand_series == 0) return fail(QCD_ERR_INVALID, "RANDSERIES = 0 (time seed) must be resolved by the host");
+    if (p->start_mode != QCD_START_COLD && p->start_mode != QCD_START_GID)
+        return fail(QCD_ERR_UNSUPPORTED, "start mode %d: only cold (1) and gid (2) starts are implemented", p->start_mode);
+    if (p->nx_local < 1 || p->x0 < 0 || p->x0 + p->nx_local > p->L[0])
+        return fail(QCD_ERR_INVALID, "slab [%d, %d) outside 0..%d", p->x0, p->x0 + p->nx_local, p->L[0]);
+    if (p->halo != 0 && p->halo != 1) return fail(QCD_ERR_INVALID, "halo must be 0 or 1");
+    if (!p->halo && (p->x0 != 0 || p->nx_local != p->L[0]))
+        return fail(QCD_ERR_INVALID, "halo = 0 requires the context to own the whole lattice in x");
+    const long sites = (long)p->L[0] * p->L[1] * p->L[2] * p->L[3];
+    if (sites > (1L << 30)) return fail(QCD_ERR_UNSUPPORTED, "lattice of %ld sites exceeds 2^30", sites);
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (p->device < 0 || p->device >= ndev) return fail(QCD_ERR_INVALID, "device %d of %d", p->device, ndev);
+    HIP_TRY(hipSetDevice(p->device));
+
+    qcd_ctx* c = new qcd_ctx();
+    memset(c, 0, sizeof(*c));
+    c->p = *p;
+    Geom& g = c->g;
+    g.nx = p->nx_local; g.ny = p->L[1]; g.nz = p->L[2]; g.nt = p->L[3];
+    g.halo = p->halo;
+    g.x0 = p->x0;
+    g.nyh = g.ny / 2;
+    g.slice_h = g.nyh * g.nz * g.nt;
+    g.vh_int = g.nx * g.slice_h;
+    g.vh_alloc = (g.nx + 2 * g.halo) * g.slice_h;
+    g.gsites = (int)sites;
+    g.gslice = g.ny * g.nz * g.nt;
+    c->ncomp = (p->group == 3) ? 6 : 2;
+    c->U_elems = (size_t)8 * c->ncomp * g.vh_alloc;
+    c->npartial = cdiv(2L * g.vh_int, MEAS_BLOCK);
+
+    int rc = QCD_OK;
+    auto tryhip = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == QCD_OK) rc = fail(e == hipErrorOutOfMemory ? QCD_ERR_NOMEM : QCD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    tryhip(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+    c->stream = c->own_stream;
+    tryhip(hipEventCreate(&c->ev0), "hipEventCreate");
+    tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
+    tryhip(hipMalloc(&c->U, c->U_elems * sizeof(double2)), "hipMalloc(links)");
+    const size_t stw = (size_t)RLX_STATE_WORDS * g.vh_int * sizeof(unsigned);
+    tryhip(hipMalloc(&c->rv.slot[0], stw), "hipMalloc(ranlux)");
+    tryhip(hipMalloc(&c->rv.slot[1], stw), "hipMalloc(ranlux)");
+    tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh_int * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
+    c->rv.ns = g.vh_int;
+    if (p->start_mode == QCD_START_GID)
+        tryhip(hipMalloc(&c->gidr, (size_t)6 * g.nx * g.gslice * sizeof(float)), "hipMalloc(gid table)");
+    tryhip(hipMalloc(&c->partial, (size_t)2 * c->npartial * sizeof(double2)), "hipMalloc(partials)");
+    tryhip(hipMalloc(&c->result_dev, 8 * sizeof(double)), "hipMalloc(result)");
+    tryhip(hipHostMalloc(&c->result_host, 8 * sizeof(double)), "hipHostMalloc(result)");
+    tryhip(hipMalloc(&c->draws_dev, sizeof(unsigned long long)), "hipMalloc(draws)");
+    tryhip(hipHostMalloc(&c->draws_host, sizeof(unsigned long long)), "hipHostMalloc(draws)");
+    if (rc != QCD_OK) {
+        qcd_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return QCD_OK;
+}
+
+void qcd_destroy(qcd_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->p.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->U);
+    (void)hipFree(c->rv.slot[0]);
+    (void)hipFree(c->rv.slot[1]);
+    (void)hipFree(c->rv.ctl);
+    (void)hipFree(c->gidr);
+    (void)hipFree(c->partial);
+    (void)hipFree(c->result_dev);
+    (void)hipFree(c->draws_dev);
+    if (c->result_host) (void)hipHostFree(c->result_host);
+    if (c->draws_host) (void)hipHostFree(c->draws_host);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int qcd_set_stream(qcd_ctx* c, void* hip_stream)
+{
+    int rc = check_ctx(c, false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return QCD_OK;
+}
+
+int qcd_synchronize(qcd_ctx* c)
+{
+    int rc = check_ctx(c, false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QCD_OK;
+}
+
+int qcd_init_lattice(qcd_ctx* c)
+{
+    int rc = check_ctx(c, false);
+    if (rc) return rc;
+    const Geom& g = c->g;
+    if (c->p.start_mode == QCD_START_COLD) {
+        const dim3 grid(cdiv((long)c->U_elems, MEAS_BLOCK) > 4096 ? 4096 : cdiv((long)c->U_elems, MEAS_BLOCK)), block(MEAS_BLOCK);
+        if (c->p.group == 3) hipLaunchKernelGGL((k_init_cold<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g);
+        else hipLaunchKernelGGL((k_init_cold<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // links of the owned slices and, for a slab, of the two halo slices
+        rc = upload_gid_slices(c, c->p.x0 - g.halo, 0, g.nx + 2 * g.halo);
+        if (rc) return rc;
+        // closed-form random numbers of the owned sites
+        const size_t n = (size_t)g.nx * g.gslice;
+        std::vector<float> tab(6 * n);
+        for (size_t lg = 0; lg < n; lg++) {
+            float r[6];
+            gid_randoms((int)(lg + (size_t)c->p.x0 * g.gslice), c->p.nhit, g.gsites, r);
+            for (int k = 0; k < 6; k++) tab[k * n + lg] = r[k];
+        }
+        HIP_TRY(hipMemcpyAsync(c->gidr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    rc = seed_streams(c);
+    if (rc) return rc;
+    c->initialized = true;
+    return QCD_OK;
+}
+
+int qcd_update(qcd_ctx* c, int parity, int dir)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    return launch_update(c, parity, dir);
+}
+
+int qcd_sweep(qcd_ctx* c, int n)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (c->g.halo) return fail(QCD_ERR_STATE, "qcd_sweep on a slab context: the halo exchange between passes is the caller's");
+    for (int s = 0; s < n; s++) {
+        for (int dir = 0; dir < 4; dir++)
+            if ((rc = launch_update(c, 1, dir))) return rc;
+        for (int dir = 0; dir < 4; dir++)
+            if ((rc = launch_update(c, 0, dir))) return rc;
+    }
+    return QCD_OK;
+}
+
+int qcd_reunitarize(qcd_ctx* c)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    Timed tm(c, 1);
+    const dim3 grid(cdiv(2L * c->g.vh_int, MEAS_BLOCK)), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_reunit<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g);
+    else hipLaunchKernelGGL((k_reunit<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g);
+    return tm.finish();
+}
+
+int qcd_measure_plaquette_sums(qcd_ctx* c, double sums[2])
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (!sums) return fail(QCD_ERR_INVALID, "null output");
+    Timed tm(c, 1);
+    const dim3 grid(c->npartial), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial);
+    else hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial);
+    if ((rc = tm.finish())) return rc;
+    return reduce_partials(c, c->npartial, 1, sums);
+}
+
+int qcd_measure_plaquette(qcd_ctx* c, double out[3])
+{
+    if (c && c->g.halo) return fail(QCD_ERR_STATE, "normalised measurement on a slab: add the *_sums of all contexts instead");
+    double s[2];
+    int rc = qcd_measure_plaquette_sums(c, s);
+    if (rc) return rc;
+    // SU(N)/suncpp/Measurements/Plq.h:90-92 with nd = 4
+    const double v = (double)c->g.gsites;
+    out[2] = (s[0] + s[1]) / (6 * v);
+    out[0] = s[0] / (3 * v);
+    out[1] = s[1] / (3 * v);
+    return QCD_OK;
+}
+
+int qcd_measure_action(qcd_ctx* c, double out[3])
+{
+    double plq[3];
+    int rc = qcd_measure_plaquette(c, plq);
+    if (rc) return rc;
+    // SU(N)/suncpp/Measurements/S.h:92-97
+    for (int i = 0; i < 3; i++) out[i] = c->p.beta * (1 - plq[i] / c->p.group);
+    return QCD_OK;
+}
+
+int qcd_measure_polyakov_sums(qcd_ctx* c, double sums[4])
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (!sums) return fail(QCD_ERR_INVALID, "null output");
+    const int n3 = c->g.nx * c->g.ny * c->g.nz;
+    const int nb = cdiv(n3, MEAS_BLOCK);
+    if (nb > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
+    Timed tm(c, 1);
+    const dim3 grid(nb), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_polyakov<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb);
+    else hipLaunchKernelGGL((k_polyakov<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb);
+    if ((rc = tm.finish())) return rc;
+    return reduce_partials(c, nb, 2, sums);
+}
+
+int qcd_measure_polyakov(qcd_ctx* c, double out[4])
+{
+    if (c && c->g.halo) return fail(QCD_ERR_STATE, "normalised measurement on a slab: add the *_sums of all contexts instead");
+    double s[4];
+    int rc = qcd_measure_polyakov_sums(c, s);
+    if (rc) return rc;
+    // SU(N)/suncl/su3cpu.cpp:1427-1430
+    const double n3 = (double)c->p.L[0] * c->p.L[1] * c->p.L[2];
+    const double n = c->p.group;
+    out[0] = s[0] / (n3 * n);
+    out[1] = s[1] / (n3 * n);
+    out[2] = s[2] / (n3 * n * n);
+    out[3] = s[3] / (n3 * n * n * n * n);
+    return QCD_OK;
+}
+
+static int transfer(qcd_ctx* c, void* host, size_t bytes, int rowsize, bool up)
+{
+    int rc = check_ctx(c, !up);
+    if (rc) return rc;
+    const Geom& g = c->g;
+    const int rows = (c->p.group == 3) ? 12 : 4;
+    const long nsite = (long)g.nx * g.gslice;
+    if (!host) return fail(QCD_ERR_INVALID, "null host table");
+    if (rowsize < nsite) return fail(QCD_ERR_INVALID, "rowsize %d < owned sites %ld", rowsize, nsite);
+    const size_t need = (size_t)rows * rowsize * 4 * sizeof(double);
+    if (bytes != need) return fail(QCD_ERR_INVALID, "table is %zu bytes, expected rows*rowsize*32 = %zu", bytes, need);
+    double4* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, need));
+    hipError_t e = hipSuccess;
+    if (up) {
+        e = hipMemcpyAsync(dev, host, need, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) rc = convert_slices(c, dev, rowsize, g.halo, g.nx, true);
+    } else {
+        e = hipMemsetAsync(dev, 0, need, c->stream);
+        if (e == hipSuccess) rc = convert_slices(c, dev, rowsize, g.halo, g.nx, false);
+        if (e == hipSuccess && rc == QCD_OK) e = hipMemcpyAsync(host, dev, need, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(QCD_ERR_HIP, "copy: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(QCD_ERR_HIP, "sync: %s", hipGetErrorString(e2));
+    if (rc) return rc;
+    if (up && !c->initialized) {
+        // a configuration supplied by the caller: streams start from their seeds
+        if (c->p.start_mode == QCD_START_GID) return fail(QCD_ERR_STATE, "upload before qcd_init_lattice in gid mode");
+        rc = seed_streams(c);
+        if (rc) return rc;
+        c->initialized = true;
+    }
+    return QCD_OK;
+}
+
+int qcd_upload(qcd_ctx* c, const void* host_table, size_t bytes, int rowsize)
+{
+    return transfer(c, const_cast<void*>(host_table), bytes, rowsize, true);
+}
+
+int qcd_download(qcd_ctx* c, void* host_table, size_t bytes, int rowsize)
+{
+    return transfer(c, host_table, bytes, rowsize, false);
+}
+
+size_t qcd_halo_bytes(const qcd_ctx* c)
+{
+    if (!c) return 0;
+    return (size_t)c->ncomp * c->g.slice_h * sizeof(double2);
+}
+
+static int halo_op(qcd_ctx* c, int side, int dir, int parity, void* buf, bool pack)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (!c->g.halo) return fail(QCD_ERR_STATE, "context has no halo slices");
+    if (side != 0 && side != 1) return fail(QCD_ERR_INVALID, "side %d", side);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    if (!buf) return fail(QCD_ERR_INVALID, "null buffer");
+    // stored slices: 0 = left halo, 1..nx = owned, nx+1 = right halo
+    const int slice = pack ? (side == 0 ? 1 : c->g.nx) : (side == 0 ? 0 : c->g.nx + 1);
+    Timed tm(c, 2);
+    const dim3 grid(cdiv((long)c->ncomp * c->g.slice_h, MEAS_BLOCK)), block(MEAS_BLOCK);
+    if (c->p.group == 3) {
+        if (pack) hipLaunchKernelGGL((k_halo<3, true, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        else hipLaunchKernelGGL((k_halo<3, false, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+    } else {
+        if (pack) hipLaunchKernelGGL((k_halo<2, true, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        else hipLaunchKernelGGL((k_halo<2, false, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+    }
+    return tm.finish();
+}
+
+int qcd_halo_pack(qcd_ctx* c, int side, int dir, int parity, void* dev_buf)
+{
+    return halo_op(c, side, dir, parity, dev_buf, true);
+}
+
+int qcd_halo_unpack(qcd_ctx* c, int side, int dir, int parity, const void* dev_buf)
+{
+    return halo_op(c, side, dir, parity, const_cast<void*>(dev_buf), false);
+}
+
+int qcd_set_profiling(qcd_ctx* c, int on)
+{
+    int rc = check_ctx(c, false);
+    if (rc) return rc;
+    c->profiling = on != 0;
+    return QCD_OK;
+}
+
+int qcd_get_timing(qcd_ctx* c, qcd_timing* out)
+{
+    if (!c || !out) return fail(QCD_ERR_INVALID, "null argument");
+    *out = c->timing;
+    return QCD_OK;
+}
+
+int qcd_timed_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* launches)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (n < 1 || !elapsed_ms) return fail(QCD_ERR_INVALID, "bad arguments");
+    if (c->profiling) return fail(QCD_ERR_STATE, "per-launch profiling is on: switch it off for a bracketed timing");
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    const unsigned long long before = c->timing.update_launches;
+    HIP_TRY(hipEventRecord(a, c->stream));
+    rc = qcd_sweep(c, n);
+    hipError_t e = hipEventRecord(b, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(QCD_ERR_HIP, "event timing: %s", hipGetErrorString(e));
+    *elapsed_ms = ms;
+    if (launches) *launches = c->timing.update_launches - before;
+    return QCD_OK;
+}
+
+int qcd_rng_draws(qcd_ctx* c, unsigned long long* draws)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (!draws) return fail(QCD_ERR_INVALID, "null output");
+    HIP_TRY(hipMemcpyAsync(c->draws_host, c->draws_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *draws = *c->draws_host;
+    return QCD_OK;
+}
+
+// ---- host-only helpers exported for the CPU test-suite (no device needed) -------------------
+
+// n values of stream `stream` produced by the batch formulation the kernels use
+int qcd_host_ranlux_stream(unsigned rand_series, int stream, int lux_level, int n, float* out)
+{
+    if (!out || n < 0 || stream < 0) return fail(QCD_ERR_INVALID, "bad arguments");
+    const int nskip = rlx_nskip_for_level(lux_level);
+    std::vector<int> seeds = stream_seeds(rand_series, stream, 1);
+    RlxRegs r;
+    rlx_seed_state(seeds[0], nskip, r);
+    float batch[24];
+    int produced = 0;
+    while (produced < n) {
+        rlx_batch(r, batch, 1);
+        for (int k = 0; k < 24 && produced < n; k++) out[produced++] = batch[k];
+        rlx_skip(r, nskip / 24, nskip % 24);
+    }
+    return QCD_OK;
+}
+
+// the closed-form gid tables, as uploaded by qcd_init_lattice
+int qcd_host_gid_link(int group, int gid, int dir, int sites, double quads[12])
+{
+    if (!quads) return fail(QCD_ERR_INVALID, "null output");
+    gid_link(group, gid, dir, sites, quads);
+    return QCD_OK;
+}
+
+int qcd_host_gid_randoms(int gid, int nhit, int sites, float out[6])
+{
+    if (!out) return fail(QCD_ERR_INVALID, "null output");
+    gid_randoms(gid, nhit, sites, out);
+    return QCD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+// lattice.h -- data layout of the link table in HBM and the index maps of the kernels.
+//
+// Site numbering is the reference's: gid = y + z*Ny + t*Ny*Nz + x*Ny*Nz*Nt, y fastest and x
+// slowest (SU(N)/suncpp/coord_work/coord_work.cpp:40-61).  Sites 2h and 2h+1 differ in y only
+// (Ny is even), so they have opposite parity and "half index" h = gid >> 1 numbers the sites
+// of EITHER parity; it is also the reference's thread index of an update pass
+// (coord_work.cpp:151-175).
+//
+// Layout (differs from the reference's 4-vector rows on purpose): even/odd split,
+// component-major, one fp64 complex (16 B) per lane:
+//
+//     U[dir][parity][comp][h]      h in [0, vh_alloc),  comp in [0, NCOMP)
+//
+// NCOMP = 6 for SU(3) (rows u and v; w = (u x v)* is rebuilt in registers), 2 for SU(2)
+// (row u).  A wavefront reading component c of 64 consecutive half-sites moves 1 KiB with one
+// global_load_dwordx4 per lane; a (parity, dir) pass streams its own parity's arrays linearly.
+// A slab context (halo = 1) stores nx + 2 x-slices: slice 0 and slice nx + 1 are the halos.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "su_math.h"
+
+namespace qcd {
+
+struct Geom {
+    int nx, ny, nz, nt;  // owned (interior) extents; nx = number of owned x slices
+    int halo;            // 0 or 1
+    int x0;              // global x of owned slice 0
+    int nyh;             // ny / 2
+    int slice_h;         // half-sites per x slice = nyh*nz*nt
+    int vh_int;          // owned half-sites = nx*slice_h
+    int vh_alloc;        // stored half-sites = (nx + 2*halo)*slice_h
+    int gsites;          // sites of the FULL lattice
+    int gslice;          // sites per x slice = ny*nz*nt
+};
+
+struct Site {
+    int xs, y, z, t;  // xs: owned-slice index; -1 and nx address the halos of a slab
+};
+
+template <int GROUP>
+struct ncomp {
+    static constexpr int value = (GROUP == 3) ? 6 : 2;
+};
+
+__device__ __forceinline__ int half_index(const Geom& g, const Site& s)
+{
+    return (((s.xs + g.halo) * g.nt + s.t) * g.nz + s.z) * g.nyh + (s.y >> 1);
+}
+__device__ __forceinline__ int site_parity(const Geom& g, const Site& s)
+{
+    return (g.x0 + s.xs + s.y + s.z + s.t) & 1;
+}
+// site of parity `par` with interior half index t (t in [0, vh_int))
+__device__ __forceinline__ Site site_of(const Geom& g, int t, int par)
+{
+    Site s;
+    s.xs = t / g.slice_h;
+    int r = t - s.xs * g.slice_h;
+    const int zt = g.nyh * g.nz;
+    s.t = r / zt;
+    r -= s.t * zt;
+    s.z = r / g.nyh;
+    const int yh = r - s.z * g.nyh;
+    const int yb = (par + g.x0 + s.xs + s.z + s.t) & 1;
+    s.y = 2 * yh + yb;
+    return s;
+}
+// nearest neighbours with periodic wrap (coord_work.cpp:63-149); in a slab the x direction
+// does not wrap: the halo slices stand in for the neighbouring contexts
+__device__ __forceinline__ Site fwd(const Geom& g, Site s, int dir)
+{
+    switch (dir) {
+        case 0: s.xs++; if (!g.halo && s.xs >= g.nx) s.xs = 0; break;
+        case 1: s.y++; if (s.y >= g.ny) s.y = 0; break;
+        case 2: s.z++; if (s.z >= g.nz) s.z = 0; break;
+        default: s.t++; if (s.t >= g.nt) s.t = 0; break;
+    }
+    return s;
+}
+__device__ __forceinline__ Site bwd(const Geom& g, Site s, int dir)
+{
+    switch (dir) {
+        case 0: if (!g.halo && s.xs <= 0) s.xs = g.nx; s.xs--; break;
+        case 1: if (s.y <= 0) s.y = g.ny; s.y--; break;
+        case 2: if (s.z <= 0) s.z = g.nz; s.z--; break;
+        default: if (s.t <= 0) s.t = g.nt; s.t--; break;
+    }
+    return s;
+}
+
+template <int GROUP>
+__device__ __forceinline__ size_t comp_base(const Geom& g, int dir, int par)
+{
+    return (size_t)((dir * 2 + par) * ncomp<GROUP>::value) * (size_t)g.vh_alloc;
+}
+
+__device__ __forceinline__ su3 load_link(const double2* __restrict__ U, const Geom& g, int dir,
+                                         int par, int h, su3*)
+{
+    const double2* p = U + comp_base<3>(g, dir, par) + h;
+    su3 m;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const double2 v = p[(size_t)c * g.vh_alloc];
+        m.e[c / 3][c % 3] = mk(v.x, v.y);
+    }
+    reconstruct(m);
+    return m;
+}
+__device__ __forceinline__ su2 load_link(const double2* __restrict__ U, const Geom& g, int dir,
+                                         int par, int h, su2*)
+{
+    const double2* p = U + comp_base<2>(g, dir, par) + h;
+    su2 m;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const double2 v = p[(size_t)c * g.vh_alloc];
+        m.e[0][c] = mk(v.x, v.y);
+    }
+    reconstruct(m);
+    return m;
+}
+template <int GROUP>
+__device__ __forceinline__ mat<GROUP> load_site_link(const double2* __restrict__ U, const Geom& g,
+                                                     int dir, const Site& s)
+{
+    return load_link(U, g, dir, site_parity(g, s), half_index(g, s), (mat<GROUP>*)nullptr);
+}
+
+__device__ __forceinline__ void store_link(double2* __restrict__ U, const Geom& g, int dir, int par,
+                                           int h, const su3& m)
+{
+    double2* p = U + comp_base<3>(g, dir, par) + h;
+#pragma unroll
+    for (int c = 0; c < 6; c++) p[(size_t)c * g.vh_alloc] = make_double2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im);
+}
+__device__ __forceinline__ void store_link(double2* __restrict__ U, const Geom& g, int dir, int par,
+                                           int h, const su2& m)
+{
+    double2* p = U + comp_base<2>(g, dir, par) + h;
+#pragma unroll
+    for (int c = 0; c < 2; c++) p[(size_t)c * g.vh_alloc] = make_double2(m.e[0][c].re, m.e[0][c].im);
+}
+
+}  // namespace qcd

@@ -1,0 +1,179 @@
+// su_math.h -- register-resident SU(2)/SU(3) algebra for the gfx950 kernels.
+//
+// Every matrix lives in VGPRs as fully unrolled, statically indexed arrays of fp64 complex
+// numbers; there is no MFMA here on purpose (3x3 contractions are far below one MFMA tile).
+// The term order inside each product follows the reference's sequential CPU path
+// (SU(N)/suncpp/su3/algebra_su3.cpp:118-143, su2/algebra_su2.cpp:90-102) so that, apart from
+// fused multiply-adds, the device rounds like the CPU checker does.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace qcd {
+
+struct cplx {
+    double re, im;
+};
+
+__device__ __forceinline__ cplx mk(double re, double im)
+{
+    cplx c;
+    c.re = re;
+    c.im = im;
+    return c;
+}
+__device__ __forceinline__ cplx conj(cplx a) { return mk(a.re, -a.im); }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return mk(a.re - b.re, a.im - b.im); }
+// SU(N)/kernel/complex.h:371-376
+__device__ __forceinline__ cplx cmul(cplx a, cplx b)
+{
+    return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+
+template <int N>
+struct mat {
+    cplx e[N][N];  // e[row][col]
+};
+using su3 = mat<3>;
+using su2 = mat<2>;
+
+// one entry of a product: sum_k a_k * b_k, in the reference's term order
+__device__ __forceinline__ cplx dot3(cplx a1, cplx a2, cplx a3, cplx b1, cplx b2, cplx b3)
+{
+    cplx c;
+    c.re = -a1.im * b1.im + a1.re * b1.re - a2.im * b2.im + a2.re * b2.re - a3.im * b3.im + a3.re * b3.re;
+    c.im = a1.re * b1.im + a1.im * b1.re + a2.re * b2.im + a2.im * b2.re + a3.re * b3.im + a3.im * b3.re;
+    return c;
+}
+__device__ __forceinline__ cplx dot2(cplx a1, cplx a2, cplx b1, cplx b2)
+{
+    cplx c;
+    c.re = -a1.im * b1.im + a1.re * b1.re - a2.im * b2.im + a2.re * b2.re;
+    c.im = a1.re * b1.im + a1.im * b1.re + a2.re * b2.im + a2.im * b2.re;
+    return c;
+}
+
+__device__ __forceinline__ su3 mul(const su3& a, const su3& b)
+{
+    su3 c;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            c.e[i][j] = dot3(a.e[i][0], a.e[i][1], a.e[i][2], b.e[0][j], b.e[1][j], b.e[2][j]);
+    return c;
+}
+__device__ __forceinline__ su2 mul(const su2& a, const su2& b)
+{
+    su2 c;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) c.e[i][j] = dot2(a.e[i][0], a.e[i][1], b.e[0][j], b.e[1][j]);
+    return c;
+}
+
+template <int N>
+__device__ __forceinline__ mat<N> herm(const mat<N>& a)
+{
+    mat<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) r.e[i][j] = conj(a.e[j][i]);
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ void add_to(mat<N>& a, const mat<N>& b)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) a.e[i][j] = cadd(a.e[i][j], b.e[i][j]);
+}
+
+template <int N>
+__device__ __forceinline__ mat<N> zero()
+{
+    mat<N> r;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j < N; j++) r.e[i][j] = mk(0.0, 0.0);
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ mat<N> unity()
+{
+    mat<N> r = zero<N>();
+#pragma unroll
+    for (int i = 0; i < N; i++) r.e[i][i].re = 1.0;
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ cplx trace(const mat<N>& a)
+{
+    cplx t = a.e[0][0];
+#pragma unroll
+    for (int i = 1; i < N; i++) t = cadd(t, a.e[i][i]);
+    return t;
+}
+
+// third row from the first two: w = (u x v)*  (SU(N)/suncpp/su3/algebra_su3.cpp:219-226)
+__device__ __forceinline__ void reconstruct(su3& a)
+{
+    const cplx u1 = a.e[0][0], u2 = a.e[0][1], u3 = a.e[0][2];
+    const cplx v1 = a.e[1][0], v2 = a.e[1][1], v3 = a.e[1][2];
+    a.e[2][0].re = u3.im * v2.im - u3.re * v2.re - u2.im * v3.im + u2.re * v3.re;
+    a.e[2][0].im = u3.re * v2.im + u3.im * v2.re - u2.re * v3.im - u2.im * v3.re;
+    a.e[2][1].re = -u3.im * v1.im + u3.re * v1.re + u1.im * v3.im - u1.re * v3.re;
+    a.e[2][1].im = -u3.re * v1.im - u3.im * v1.re + u1.re * v3.im + u1.im * v3.re;
+    a.e[2][2].re = u2.im * v1.im - u2.re * v1.re - u1.im * v2.im + u1.re * v2.re;
+    a.e[2][2].im = u2.re * v1.im + u2.im * v1.re - u1.re * v2.im - u1.im * v2.re;
+}
+// second row of an SU(2) element from the first (algebra_su2.cpp:137-142)
+__device__ __forceinline__ void reconstruct(su2& a)
+{
+    a.e[1][0] = mk(-a.e[0][1].re, a.e[0][1].im);
+    a.e[1][1] = mk(a.e[0][0].re, -a.e[0][0].im);
+}
+
+// Gram-Schmidt re-unitarisation (SU(N)/suncpp/su3/algebra_su3.cpp:185-217)
+__device__ __forceinline__ void gram_schmidt(su3& a)
+{
+    cplx u1 = a.e[0][0], u2 = a.e[0][1], u3 = a.e[0][2];
+    cplx v1 = a.e[1][0], v2 = a.e[1][1], v3 = a.e[1][2];
+    const double norm_u = sqrt(u1.re * u1.re + u2.re * u2.re + u3.re * u3.re + u1.im * u1.im +
+                               u2.im * u2.im + u3.im * u3.im);
+    u1 = mk(u1.re / norm_u, u1.im / norm_u);
+    u2 = mk(u2.re / norm_u, u2.im / norm_u);
+    u3 = mk(u3.re / norm_u, u3.im / norm_u);
+    const cplx sp = cadd(cadd(cmul(v1, conj(u1)), cmul(v2, conj(u2))), cmul(v3, conj(u3)));
+    v1 = csub(v1, cmul(u1, sp));
+    v2 = csub(v2, cmul(u2, sp));
+    v3 = csub(v3, cmul(u3, sp));
+    const double norm_v = sqrt(v1.re * v1.re + v2.re * v2.re + v3.re * v3.re + v1.im * v1.im +
+                               v2.im * v2.im + v3.im * v3.im);
+    v1 = mk(v1.re / norm_v, v1.im / norm_v);
+    v2 = mk(v2.re / norm_v, v2.im / norm_v);
+    v3 = mk(v3.re / norm_v, v3.im / norm_v);
+    a.e[0][0] = u1; a.e[0][1] = u2; a.e[0][2] = u3;
+    a.e[1][0] = v1; a.e[1][1] = v2; a.e[1][2] = v3;
+    reconstruct(a);
+}
+// SU(2): normalise the first row, rebuild the second (kernel lattice_GramSchmidt,
+// SU(N)/suncl/suncl.cl:349-396 with lattice_su2_Normalize)
+__device__ __forceinline__ void gram_schmidt(su2& a)
+{
+    cplx u1 = a.e[0][0], u2 = a.e[0][1];
+    const double n = sqrt(u1.re * u1.re + u1.im * u1.im + u2.re * u2.re + u2.im * u2.im);
+    a.e[0][0] = mk(u1.re / n, u1.im / n);
+    a.e[0][1] = mk(u2.re / n, u2.im / n);
+    reconstruct(a);
+}
+
+}  // namespace qcd

@@ -128,6 +128,18 @@ class Lattice:
         lib.qo_import_device_layout(self.h, t.ctypes.data_as(C.POINTER(C.c_double)), t.shape[1])
 
 
+class _LatticeHead(C.Structure):
+    # leading fields of qo_lattice up to rng_draws (oracle/qcd_oracle.h)
+    _fields_ = [("group", C.c_int), ("nd", C.c_int), ("L", C.c_int * 4), ("sites", C.c_int),
+                ("nhit", C.c_int), ("beta", C.c_double), ("ints", C.c_int), ("rng_mode", C.c_int),
+                ("nskip", C.c_int), ("randseries", C.c_uint), ("links", C.c_void_p),
+                ("seq", RanluxState), ("streams", C.c_void_p), ("rng_draws", C.c_ulonglong)]
+
+
+def rng_draws(lat):
+    return C.cast(lat.h, C.POINTER(_LatticeHead)).contents.rng_draws
+
+
 def simulate(group, L, beta, nhit, ints, rng_mode, lux, seed, nav, iter_, niter):
     h = lib.qo_create(group, _L(L), beta, nhit, ints, rng_mode, lux, seed)
     plq = np.zeros((iter_, 3))

@@ -1,0 +1,182 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU checker and the golden vectors.
+
+Tolerances (fp64): the device fuses multiply-adds and uses its own libm, so single links agree
+with the checker to rounding (1e-13 after one pass); lattice averages are required to agree to
+1e-12 relative -- the bar the north star states for the plaquette -- over the few sweeps for
+which a chaotic Markov chain can be compared at all.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12
+
+
+def _ctx(**kw):
+    import qcdgpu_amd as q
+    return q.Context(**kw)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+@pytest.mark.parametrize("group", [2, 3])
+def test_cold_start_known_answers(group):
+    with _ctx(group=group, L=(4, 6, 4, 8), beta=6.0) as c:
+        c.init_lattice()
+        assert np.all(c.plaquette() == float(group))
+        assert np.all(c.action() == 0.0)
+        p = c.polyakov()
+        assert p[0] == 1.0 and p[1] == 0.0 and p[2] == 1.0 and p[3] == 1.0
+
+
+@pytest.mark.parametrize("group", [2, 3])
+def test_gid_start_links_bit_exact_and_layout_roundtrip(group):
+    import qcdgpu_amd as q
+    L = (4, 6, 8, 4)
+    with _ctx(group=group, L=L, beta=6.0, start_mode=q.START_GID) as c:
+        c.init_lattice()
+        lat = ol.Lattice(group, L, 6.0, ints=2, rng_mode=ol.RNG_GID)
+        want = lat.export_table()
+        got = c.download()
+        # closed-form start evaluated with the host libm on both sides; compilers differ in
+        # whether sin(a), cos(a) of one argument become one sincos() call, which moves a few
+        # entries by one ulp
+        assert np.max(np.abs(got - want)) < 4e-16
+        assert _rel(c.plaquette(), lat.plaquette()) < 1e-13
+        assert np.allclose(c.polyakov(), lat.polyakov(), rtol=1e-12, atol=1e-15)
+        # upload of a padded table (ROWSIZE > sites) and download again
+        rowsize = lat.sites + 192
+        t = lat.export_table(rowsize)
+    with _ctx(group=group, L=L, beta=6.0) as c2:
+        c2.upload(t)
+        assert np.array_equal(c2.download(rowsize)[:, :lat.sites], want)   # pure data movement
+    lat.close()
+
+
+@pytest.mark.parametrize("group", [2, 3])
+def test_every_pass_matches_checker_link_by_link(group):
+    """gid mode, one (parity, direction) pass at a time: every link against the checker."""
+    import qcdgpu_amd as q
+    L = (4, 4, 6, 4)
+    beta = 6.0 if group == 3 else 2.4
+    lat = ol.Lattice(group, L, beta, nhit=10, ints=2, rng_mode=ol.RNG_GID)
+    with _ctx(group=group, L=L, beta=beta, nhit=10, start_mode=q.START_GID) as c:
+        c.init_lattice()
+        for parity in (1, 0):
+            for d in range(4):
+                c.update(parity, d)
+                lat.update(parity, d)
+                got, want = c.download(), lat.export_table()
+                assert np.max(np.abs(got - want)) < 1e-12, (parity, d)
+    lat.close()
+
+
+GID_CASES = [c for c in ol.golden_cases() if c.endswith("_gid.json")]
+
+
+@pytest.mark.parametrize("case", GID_CASES)
+def test_gid_runs_match_reference_vectors(case):
+    """Deterministic (INTS = 2) runs against the vectors minted from the compiled reference."""
+    import qcdgpu_amd as q
+    fx = ol.golden(case)
+    a = ol.init_to_args(fx["init"])
+    with _ctx(group=a["group"], L=a["L"], beta=a["beta"], nhit=a["nhit"], start_mode=q.START_GID,
+              lux_level=a["lux"], rand_series=a["seed"]) as c:
+        c.init_lattice()
+        rows = [np.concatenate([c.plaquette(), c.action()])]
+        c.sweep(a["nav"])
+        for _ in range(1, a["iter_"]):
+            c.sweep(a["niter"])
+            rows.append(np.concatenate([c.plaquette(), c.action()]))
+    for got, want in zip(rows, fx["samples"]):
+        for g, w in zip(got, want):
+            if w is None or (isinstance(w, float) and math.isnan(w)):
+                assert math.isnan(g)
+            else:
+                # fixtures carry 14 significant digits
+                assert abs(g - w) <= 2e-13 * abs(w) + 1e-13, (case, g, w)
+
+
+@pytest.mark.parametrize("group,L,beta,nhit,lux,seed", [
+    (3, (8, 8, 8, 8), 6.0, 10, 3, 54),
+    (3, (4, 6, 8, 10), 5.5, 3, 0, 1234),
+    (3, (6, 4, 4, 6), 1.5, 2, 4, 99),      # low beta: many rejected trials, batch refills
+    (2, (8, 8, 8, 8), 2.5, 10, 3, 54),
+    (2, (6, 8, 4, 10), 1.2, 2, 2, 7),
+])
+def test_ranlux_runs_match_checker(group, L, beta, nhit, lux, seed):
+    """Production RNG mode: one RANLUX stream per thread.  Same streams on both sides, so the
+    accept/reject history (count of numbers drawn) is identical and the averages agree."""
+    lat = ol.Lattice(group, L, beta, nhit=nhit, ints=1, rng_mode=ol.RNG_PERSITE, lux=lux, seed=seed)
+    with _ctx(group=group, L=L, beta=beta, nhit=nhit, lux_level=lux, rand_series=seed) as c:
+        c.init_lattice()
+        for sweep in range(3):
+            c.sweep(1)
+            lat.sweep(1)
+            assert c.rng_draws() == ol.rng_draws(lat), sweep
+            assert _rel(c.plaquette(), lat.plaquette()) < REL, sweep
+            assert _rel(c.action(), lat.action()) < 1e-10   # S = beta(1 - Plq/N): cancellation
+        assert np.allclose(c.polyakov(), lat.polyakov(), rtol=1e-10, atol=1e-13)
+        got, want = c.download(), lat.export_table()
+        assert np.max(np.abs(got - want)) < 1e-10
+    lat.close()
+
+
+def test_config1_su3_16_plaquette_vs_cpu():
+    """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
+    L = (16, 16, 16, 16)
+    lat = ol.Lattice(3, L, 6.0, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE)
+    with _ctx(group=3, L=L, beta=6.0, nhit=10) as c:
+        c.init_lattice()
+        for sweep in range(2):
+            c.sweep(1)
+            lat.sweep(1)
+            assert c.rng_draws() == ol.rng_draws(lat)
+            assert _rel(c.plaquette(), lat.plaquette()) < REL
+    lat.close()
+
+
+def test_reunitarize_restores_unitarity():
+    import qcdgpu_amd as q
+    L = (4, 4, 4, 4)
+    lat = ol.Lattice(3, L, 6.0, ints=2, rng_mode=ol.RNG_GID)
+    t = lat.export_table()
+    rng = np.random.default_rng(1)
+    noisy = t + 1e-3 * rng.standard_normal(t.shape)
+    with _ctx(group=3, L=L, beta=6.0) as c:
+        c.upload(noisy)
+        c.reunitarize()
+        lat.import_table(c.download())
+        # after Gram-Schmidt every plaquette is a product of unitary matrices: |ReTr| <= 3
+        p = lat.plaquette()
+        assert np.all(np.abs(p) <= 3.0)
+        c.reunitarize()
+        again = c.download()
+        assert np.max(np.abs(again - lat.export_table())) < 1e-14   # idempotent
+    lat.close()
+
+
+def test_errors_are_status_codes_not_exits():
+    import qcdgpu_amd as q
+    with pytest.raises(q.QcdError):
+        _ctx(group=4, L=(4, 4, 4, 4), beta=1.0)
+    with pytest.raises(q.QcdError):
+        _ctx(group=3, L=(4, 5, 4, 4), beta=1.0)          # odd Ny
+    with pytest.raises(q.QcdError):
+        _ctx(group=3, L=(4, 4, 4, 4), beta=1.0, start_mode=q.START_HOT)
+    with _ctx(group=3, L=(4, 4, 4, 4), beta=1.0) as c:
+        with pytest.raises(q.QcdError):
+            c.sweep(1)                                    # before init
+        c.init_lattice()
+        with pytest.raises(q.QcdError):
+            c.update(2, 0)
+        with pytest.raises(q.QcdError):
+            c.upload(np.zeros((12, 100, 4)))              # rowsize < sites
