@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- link-updates/s of the SU(3) heat-bath sweep on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one full sweep (8 passes: odd/even x X,Y,Z,T) of heat-bath + re-unitarisation over a
+32^4 SU(3) fp64 lattice per GPU (weak scaling: N GPUs hold a (32N) x 32^3 lattice cut into x-slabs,
+halos exchanged over RCCL after every pass).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_LINK_UPDATE_SU3_F64 = 864     # 8 link reads + 1 link write, 12 reals of 8 B each
+HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak
+
+
+def cpu_baseline(log):
+    """Times the CPU path on this host: the reference's own binary (oracle/_ref, one thread, as
+    the reference is single-threaded) when it travelled with the tree, else this repo's C port.
+    Bounded sample: SU(3) 16^4, beta 6, NHIT 10, cold start, 8 sweeps (~10 s)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "qcdgpu_cpu")
+    sweeps, L = 8, 16
+    sites = L ** 4
+    out = None
+    if os.path.exists(ref):
+        try:
+            def run(nav):
+                tmp = tempfile.mkdtemp(prefix="qcdbench_")
+                with open(os.path.join(tmp, "init.dat"), "w") as f:
+                    f.write("GROUP = 3\nND = 4\nLS = %d\nLT = %d\nBETA = 6.0\nNHIT = 10\nINTS = 1\n"
+                            "PRNG = RANLUX3\nRANDSERIES = 54\nNAV = %d\nITER = 1\nNITER = 1\n"
+                            "OUTPUTPATH = %s/\n" % (L, L, nav, tmp))
+                t0 = time.perf_counter()
+                subprocess.run([ref, os.path.join(tmp, "init.dat")], check=True, cwd=tmp,
+                               stdout=subprocess.DEVNULL, timeout=300)
+                return time.perf_counter() - t0
+            t_meas = run(0)            # initialisation + one measurement
+            t_all = run(sweeps)        # the same + `sweeps` thermalisation sweeps
+            dt = max(t_all - t_meas, 1e-9)
+            out = {"value": 4.0 * sites * sweeps / dt, "unit": "link-updates/s", "cores": 1,
+                   "kind": "reference",
+                   "sample": "reference suncpp binary, SU(3) %d^4 beta=6.0 NHIT=10 cold RANLUX3, "
+                             "%d sweeps, %.1f s" % (L, sweeps, dt)}
+        except Exception as e:  # noqa: BLE001
+            log("reference binary not usable here (%s); timing the C port instead" % e)
+    if out is None:
+        cli = os.path.join(ROOT, "oracle", "qcd_oracle_cli")
+        if not os.path.exists(cli):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "qcd_oracle_cli"], check=True,
+                           stdout=subprocess.DEVNULL)
+        tmp = tempfile.mkdtemp(prefix="qcdbench_")
+        with open(os.path.join(tmp, "init.dat"), "w") as f:
+            f.write("GROUP = 3\nND = 4\nLS = %d\nLT = %d\nBETA = 6.0\nNHIT = 10\nINTS = 1\n"
+                    "PRNG = RANLUX3\nRANDSERIES = 54\n" % (L, L))
+        r = subprocess.run([cli, os.path.join(tmp, "init.dat"), "--time-sweeps", str(2 * sweeps)],
+                           check=True, capture_output=True, text=True, timeout=300)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        out = {"value": j["link_updates_per_s"], "unit": "link-updates/s", "cores": 1, "kind": "port",
+               "sample": "C restatement of suncpp, SU(3) %d^4 beta=6.0 NHIT=10 cold RANLUX3, %d sweeps, "
+                         "%.1f s" % (L, j["sweeps"], j["seconds"])}
+    return out
+
+
+def measured_traffic():
+    """HBM bytes per update launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(p):
+        try:
+            with open(p) as f:
+                return json.load(f).get("hbm_bytes_per_update_launch")
+        except Exception:  # noqa: BLE001
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--L", type=int, default=32, help="lattice extent per GPU (Nx per GPU, Ny, Nz, Nt)")
+    ap.add_argument("--beta", type=float, default=6.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (args.gpus, args.gpus))
+        sys.exit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    import torch
+    import qcdgpu_amd as q   # raises if the HIP library is missing: no fallback
+    from qcdgpu_amd import biglattice as bl
+
+    if not torch.cuda.is_available():
+        sys.exit("no GPU visible")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.L
+    L = (n * world, n, n, n)
+    sites_per_gpu = n ** 4
+    kw = dict(nhit=10, start_mode=q.START_COLD, lux_level=3, rand_series=54)
+
+    if world == 1:
+        ctx = q.Context(group=3, L=L, beta=args.beta, device=local_rank, **kw)
+        ctx.init_lattice()
+        sweep = ctx.sweep
+        plaquette = ctx.plaquette
+        sync = ctx.synchronize
+    else:
+        lat = bl.make_rank_slab(3, L, args.beta, rank, world, local_rank, **kw)
+        ctx = lat.engines[0].ctx
+        sweep = lat.sweep
+        plaquette = lat.plaquette
+
+        def sync():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sync()
+        torch.cuda.synchronize()
+
+    log("warm-up: %d sweeps of %dx%dx%dx%d SU(3) fp64 on %d GPU(s)" % ((args.warmup,) + L + (world,)))
+    sweep(args.warmup)
+    barrier()
+    launches0 = ctx.timing().update_launches
+    t0 = time.perf_counter()
+    if world == 1:
+        ev_ms, _ = ctx.timed_sweeps(args.steps)      # HIP events on the library's own stream
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sweep(args.steps)
+        e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        ev_ms = e0.elapsed_time(e1)
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    launches = ctx.timing().update_launches - launches0
+    plq = plaquette()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    link_updates = 4.0 * sites_per_gpu * world * args.steps
+    value = link_updates / dt
+    # dominant kernel: k_update, V/2 link updates per launch; average launch duration from the
+    # device-side event bracket around the timed sweeps (it contains nothing but those launches
+    # on one GPU; with slabs it also contains the halo traffic, so the fraction is conservative)
+    per_launch_s = (ev_ms * 1e-3) / max(launches, 1)
+    bytes_per_launch = BYTES_PER_LINK_UPDATE_SU3_F64 * sites_per_gpu / 2
+    achieved = bytes_per_launch / per_launch_s / 1e9
+    result = {
+        "metric": "link-updates/sec + mean plaquette, 32^4 SU(3) at 1/2/4/8 GPUs",
+        "value": value,
+        "unit": "link-updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (cold start, beta=%.2f Markov chain, RANLUX3 per-thread streams, seed 54)" % args.beta,
+        "config": {"workload": "SU(3) %dx%dx%dx%d heat-bath sweep (NHIT=10, re-unitarised), %d^4 per GPU"
+                               % (L + (n,)), "lattice": list(L), "beta": args.beta, "nhit": 10,
+                   "prng": "RANLUX3", "parallelism": "x-slabs x%d" % world},
+        "mean_plaquette": {"Plq_spat": plq[0], "Plq_temp": plq[1], "Plq_total": plq[2],
+                           "after_sweeps": args.warmup + args.steps},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
+                     "kernel": "k_update", "launches": int(launches),
+                     "avg_launch_us": 1e6 * per_launch_s,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+    }
+    if world == 1 and not args.no_cpu:
+        log("CPU baseline leg (bounded sample, one core)")
+        result["cpu_baseline"] = cpu_baseline(log)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,239 @@
+"""BigLattice: one lattice cut into x-slabs, one slab per rank, halo slices exchanged after
+every update pass.
+
+This is the host side of the reference's multi-device mode (SubLattice array + model::UpdateEdges,
+SU(N)/suncl/suncl.cpp:4005-4061 and :5026-5138) re-designed for one process per GPU: the slab
+geometry is the reference's (x is the slowest index, so a boundary slice is one contiguous run
+per component), the transport is torch.distributed point-to-point (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests) instead of map/memcpy/unmap through host memory.
+
+What travels.  A (parity p, direction d) pass rewrites U_d on the sites of parity p only, so after
+it exactly that half of a boundary slice is stale in the neighbour's halo:
+  * last owned slice  -> RIGHT neighbour's left halo   (every d: the backward staples read
+                         U_x, U_d and U_x(+d) one slice to the left);
+  * first owned slice -> LEFT neighbour's right halo   (d = Y, Z, T only: nothing ever reads
+                         U_x one slice to the right).
+One message is NCOMP x (Ny/2 * Nz * Nt) fp64 complex numbers: 1.5 MiB for SU(3) at 32^3.
+
+Random numbers.  RANLUX stream i belongs to the GLOBAL half-site index i, whichever rank owns it,
+so a run gives the same configuration for every way of cutting the lattice.
+"""
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+X, Y, Z, T = 0, 1, 2, 3
+
+
+def split_even(nx: int, parts: int) -> List[int]:
+    """nx slices over `parts` slabs, every slab an even number of slices (checkerboard parity
+    is taken from the global x, but an even cut also keeps the two parities balanced)."""
+    if nx % (2 * parts) == 0:
+        return [nx // parts] * parts
+    pairs, extra = divmod(nx // 2, parts)
+    if nx % 2 or pairs == 0:
+        raise ValueError("cannot cut Nx=%d into %d even slabs" % (nx, parts))
+    return [2 * (pairs + (1 if k < extra else 0)) for k in range(parts)]
+
+
+def messages_after_pass(direction: int):
+    """(pack side, receiving side at the neighbour, neighbour offset) of every message that a
+    pass over links of `direction` makes necessary."""
+    msgs = [(1, 0, +1)]            # last owned slice -> right neighbour's left halo
+    if direction != X:
+        msgs.append((0, 1, -1))    # first owned slice -> left neighbour's right halo
+    return msgs
+
+
+class LocalComm:
+    """All slabs in one process (several parts on one device: the way the reference's authors
+    exercised BigLattice on a single GPU, SU(N)/QCDGPU.cpp:129-134)."""
+
+    def __init__(self, engines: Sequence):
+        self.engines = list(engines)
+
+    def exchange(self, direction: int, parity: int):
+        n = len(self.engines)
+        for k, src in enumerate(self.engines):
+            for pack_side, recv_side, off in messages_after_pass(direction):
+                dst = self.engines[(k + off) % n]
+                buf = src.halo_pack(pack_side, direction, parity)
+                dst.halo_unpack(recv_side, direction, parity, buf)
+
+
+class TorchDistComm:
+    """One slab per torch.distributed rank; neighbours k-1 and k+1 on a ring."""
+
+    def __init__(self, engine, rank: int, world: int, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.engine = engine
+        self.rank, self.world = rank, world
+        self.group = group
+
+    def exchange(self, direction: int, parity: int):
+        dist = self.dist
+        ops, recvs = [], []
+        for pack_side, recv_side, off in messages_after_pass(direction):
+            peer_to = (self.rank + off) % self.world
+            peer_from = (self.rank - off) % self.world
+            out = self.engine.halo_pack(pack_side, direction, parity)
+            inp = self.engine.halo_buffer_like(out)
+            ops.append(dist.P2POp(dist.isend, out, peer_to, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, inp, peer_from, group=self.group))
+            recvs.append((recv_side, inp))
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()
+        for recv_side, inp in recvs:
+            self.engine.halo_unpack(recv_side, direction, parity, inp)
+
+    def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
+        import torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64), device=self.engine.reduce_device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+
+class GpuSlabEngine:
+    """A qcd_ctx slab whose halo messages live in torch CUDA tensors (plumbing only: torch owns
+    the message buffers and the stream; all lattice work is the HIP library's)."""
+
+    def __init__(self, ctx, device_index: int):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.device = torch.device("cuda", device_index)
+        self.nelem = ctx.halo_bytes() // 8
+        # order the library's kernels with the RCCL calls torch issues
+        ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self._pool = {}
+
+    def _buf(self, key):
+        if key not in self._pool:
+            self._pool[key] = self.torch.empty(self.nelem, dtype=self.torch.float64, device=self.device)
+        return self._pool[key]
+
+    def update(self, parity, direction):
+        self.ctx.update(parity, direction)
+
+    def halo_pack(self, side, direction, parity):
+        buf = self._buf(("out", side))
+        self.ctx.halo_pack(side, direction, parity, buf.data_ptr())
+        return buf
+
+    def halo_buffer_like(self, out):
+        return self._buf(("in", id(out)))
+
+    def halo_unpack(self, side, direction, parity, buf):
+        self.ctx.halo_unpack(side, direction, parity, buf.data_ptr())
+
+    def plaquette_sums(self):
+        return self.ctx.plaquette_sums()
+
+    def polyakov_sums(self):
+        return self.ctx.polyakov_sums()
+
+    def reduce_device(self):
+        return self.device
+
+
+class BigLattice:
+    """Sweep driver over slabs.  `engines` are this process's slabs, `comm` moves the halos."""
+
+    def __init__(self, engines: Sequence, comm, group: int, L: Sequence[int], beta: float):
+        self.engines = list(engines)
+        self.comm = comm
+        self.group = group
+        self.L = tuple(L)
+        self.beta = beta
+        self.sites = int(np.prod(L))
+
+    def update(self, parity: int, direction: int):
+        for e in self.engines:
+            e.update(parity, direction)
+        self.comm.exchange(direction, parity)
+
+    def sweep(self, n: int = 1):
+        # reference order: odd X,Y,Z,T then even X,Y,Z,T (SU(N)/suncpp/suncpp.h:133-141)
+        for _ in range(n):
+            for d in (X, Y, Z, T):
+                self.update(1, d)
+            for d in (X, Y, Z, T):
+                self.update(0, d)
+
+    def _global_sum(self, local: np.ndarray) -> np.ndarray:
+        if hasattr(self.comm, "allreduce_sum"):
+            return self.comm.allreduce_sum(local)
+        return local
+
+    def plaquette(self) -> np.ndarray:
+        s = np.sum([e.plaquette_sums() for e in self.engines], axis=0)
+        s = self._global_sum(s)
+        v = float(self.sites)
+        # SU(N)/suncpp/Measurements/Plq.h:90-92
+        return np.array([s[0] / (3 * v), s[1] / (3 * v), (s[0] + s[1]) / (6 * v)])
+
+    def action(self) -> np.ndarray:
+        # SU(N)/suncpp/Measurements/S.h:92-97
+        return self.beta * (1 - self.plaquette() / self.group)
+
+    def polyakov(self) -> np.ndarray:
+        s = np.sum([e.polyakov_sums() for e in self.engines], axis=0)
+        s = self._global_sum(s)
+        n3 = float(self.L[0] * self.L[1] * self.L[2])
+        g = float(self.group)
+        # SU(N)/suncl/su3cpu.cpp:1427-1430
+        return np.array([s[0] / (n3 * g), s[1] / (n3 * g), s[2] / (n3 * g * g), s[3] / (n3 * g ** 4)])
+
+
+def make_gpu_slabs(group, L, beta, nx_parts: Sequence[int], device_index: int = 0, **ctx_kw):
+    """Several slabs on ONE device, wired with LocalComm (single-GPU test of the halo logic)."""
+    from . import capi
+    engines, x0 = [], 0
+    for nx in nx_parts:
+        ctx = capi.Context(group=group, L=L, beta=beta, device=device_index, x0=x0, nx_local=nx,
+                           halo=1, **ctx_kw)
+        ctx.init_lattice()
+        engines.append(LocalGpuEngine(ctx))
+        x0 += nx
+    return BigLattice(engines, LocalComm(engines), group, L, beta)
+
+
+class LocalGpuEngine:
+    """Slab engine for LocalComm: message buffers are plain device allocations owned here."""
+
+    def __init__(self, ctx):
+        import torch
+        self.ctx = ctx
+        self.buf = torch.empty(ctx.halo_bytes() // 8, dtype=torch.float64,
+                               device=torch.device("cuda", ctx.params.device))
+        ctx.set_stream(torch.cuda.current_stream(self.buf.device).cuda_stream)
+
+    def update(self, parity, direction):
+        self.ctx.update(parity, direction)
+
+    def halo_pack(self, side, direction, parity):
+        self.ctx.halo_pack(side, direction, parity, self.buf.data_ptr())
+        return self.buf
+
+    def halo_unpack(self, side, direction, parity, buf):
+        self.ctx.halo_unpack(side, direction, parity, buf.data_ptr())
+
+    def plaquette_sums(self):
+        return self.ctx.plaquette_sums()
+
+    def polyakov_sums(self):
+        return self.ctx.polyakov_sums()
+
+
+def make_rank_slab(group, L, beta, rank: int, world: int, device_index: int, dist_group=None,
+                   **ctx_kw) -> BigLattice:
+    """This rank's slab of an L lattice cut evenly over `world` ranks (one process per GPU)."""
+    from . import capi
+    parts = split_even(L[0], world)
+    x0 = sum(parts[:rank])
+    ctx = capi.Context(group=group, L=L, beta=beta, device=device_index, x0=x0,
+                       nx_local=parts[rank], halo=1, **ctx_kw)
+    ctx.init_lattice()
+    eng = GpuSlabEngine(ctx, device_index)
+    return BigLattice([eng], TorchDistComm(eng, rank, world, dist_group), group, L, beta)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libqcdgpu_amd.so")
+LIB_PATH = os.environ.get("QCDGPU_AMD_LIB") or os.path.join(_HERE, "lib", "libqcdgpu_amd.so")
 
 START_HOT, START_COLD, START_GID = 0, 1, 2
 

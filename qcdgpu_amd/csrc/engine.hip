@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -104,31 +105,40 @@ struct Timed {
     }
 };
 
-template <int GROUP, bool GID>
+// NSKIP: 223 = RANLUX3 (the reference's default, QCDGPU.cpp:98) with the skip unrolled at compile
+// time; 0 = any luxury level, skip count at run time
+template <int GROUP, bool GID, int NSKIP>
 int launch_update_dir(qcd_ctx* c, int parity, int dir)
 {
     const Geom& g = c->g;
-    const dim3 grid(cdiv(g.vh_int, UPD_BLOCK)), block(UPD_BLOCK);
+    const dim3 grid(g.nzr * g.ntr * cdiv((long)g.nx * g.region_h, UPD_BLOCK)), block(UPD_BLOCK);
     const double beta_eff = c->p.beta / c->p.group;  // SU(N)/suncpp/Update/sun_update.h:94
+#define QCD_LAUNCH_UPDATE(D) \
+    hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, \
+                       beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev)
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_update<GROUP, 0, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
-        case 1: hipLaunchKernelGGL((k_update<GROUP, 1, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
-        case 2: hipLaunchKernelGGL((k_update<GROUP, 2, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
-        default: hipLaunchKernelGGL((k_update<GROUP, 3, GID, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev); break;
+        case 0: QCD_LAUNCH_UPDATE(0); break;
+        case 1: QCD_LAUNCH_UPDATE(1); break;
+        case 2: QCD_LAUNCH_UPDATE(2); break;
+        default: QCD_LAUNCH_UPDATE(3); break;
     }
+#undef QCD_LAUNCH_UPDATE
     return QCD_OK;
 }
 
 int launch_update(qcd_ctx* c, int parity, int dir)
 {
     const bool gid = (c->p.start_mode == QCD_START_GID);
+    const bool lux3 = (c->p.lux_level == 3);
     Timed tm(c, 0);
     if (c->p.group == 3) {
-        if (gid) launch_update_dir<3, true>(c, parity, dir);
-        else launch_update_dir<3, false>(c, parity, dir);
+        if (gid) launch_update_dir<3, true, 0>(c, parity, dir);
+        else if (lux3) launch_update_dir<3, false, 223>(c, parity, dir);
+        else launch_update_dir<3, false, 0>(c, parity, dir);
     } else {
-        if (gid) launch_update_dir<2, true>(c, parity, dir);
-        else launch_update_dir<2, false>(c, parity, dir);
+        if (gid) launch_update_dir<2, true, 0>(c, parity, dir);
+        else if (lux3) launch_update_dir<2, false, 223>(c, parity, dir);
+        else launch_update_dir<2, false, 0>(c, parity, dir);
     }
     return tm.finish();
 }
@@ -258,8 +268,8 @@ int seed_streams(qcd_ctx* c)
         for (int w = 0; w < 24; w++) st[(size_t)w * ns + i] = r.s[w];
         st[(size_t)24 * ns + i] = r.c;
     }
-    HIP_TRY(hipMemcpyAsync(c->rv.slot[0], st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->rv.slot[1], 0, st.size() * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemcpyAsync(c->rv.slot0, st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->rv.slot1, 0, st.size() * sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(c->rv.ctl, 0, (size_t)ns * sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(c->draws_dev, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -332,6 +342,23 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     g.vh_alloc = (g.nx + 2 * g.halo) * g.slice_h;
     g.gsites = (int)sites;
     g.gslice = g.ny * g.nz * g.nt;
+    // (z,t) regions for the 8 XCDs: the split with the smallest cut surface that divides both
+    // extents; none -> one region (plain linear order)
+    g.nzr = g.ntr = 1;
+    if (!getenv("QCDGPU_AMD_LINEAR_ORDER")) {  // diagnostic switch: plain linear workgroup order
+        static const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
+        double best = 1e30;
+        for (auto& cd : cand) {
+            if (g.nz % cd[0] || g.nt % cd[1]) continue;
+            const int rz = g.nz / cd[0], rt = g.nt / cd[1];
+            // fraction of a region's sites that sit on a cut face
+            const double cut = (cd[0] > 1 ? 1.0 / rz : 0.0) + (cd[1] > 1 ? 1.0 / rt : 0.0);
+            if (cut < best) { best = cut; g.nzr = cd[0]; g.ntr = cd[1]; }
+        }
+    }
+    g.rz = g.nz / g.nzr;
+    g.rt = g.nt / g.ntr;
+    g.region_h = g.nyh * g.rz * g.rt;
     c->ncomp = (p->group == 3) ? 6 : 2;
     c->U_elems = (size_t)8 * c->ncomp * g.vh_alloc;
     c->npartial = cdiv(2L * g.vh_int, MEAS_BLOCK);
@@ -346,8 +373,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
     tryhip(hipMalloc(&c->U, c->U_elems * sizeof(double2)), "hipMalloc(links)");
     const size_t stw = (size_t)RLX_STATE_WORDS * g.vh_int * sizeof(unsigned);
-    tryhip(hipMalloc(&c->rv.slot[0], stw), "hipMalloc(ranlux)");
-    tryhip(hipMalloc(&c->rv.slot[1], stw), "hipMalloc(ranlux)");
+    tryhip(hipMalloc(&c->rv.slot0, stw), "hipMalloc(ranlux)");
+    tryhip(hipMalloc(&c->rv.slot1, stw), "hipMalloc(ranlux)");
     tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh_int * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
     c->rv.ns = g.vh_int;
     if (p->start_mode == QCD_START_GID)
@@ -371,8 +398,8 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipSetDevice(c->p.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->U);
-    (void)hipFree(c->rv.slot[0]);
-    (void)hipFree(c->rv.slot[1]);
+    (void)hipFree(c->rv.slot0);
+    (void)hipFree(c->rv.slot1);
     (void)hipFree(c->rv.ctl);
     (void)hipFree(c->gidr);
     (void)hipFree(c->partial);

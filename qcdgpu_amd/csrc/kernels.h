@@ -20,52 +20,176 @@
 
 namespace qcd {
 
-// SU(N)/kernel/complex.h:200-202
-#define QCD_PI2 6.2831853071795864769252867665590
+// delivered RANLUX batches held in LDS per thread by the update kernel (2 or 3)
+#ifndef QCD_RLX_WINDOW
+#define QCD_RLX_WINDOW 3
+#endif
+constexpr int RLX_WINDOW = QCD_RLX_WINDOW;
 
 // ---------------------------------------------------------------------------------------------
 // random sources of the heat-bath
 
 struct RlxView {
-    unsigned* slot[2];  // [w * ns + stream], w in [0, 25): state in front of a batch
+    unsigned* slot0;    // [w * ns + stream], w in [0, 25): state in front of a batch
+    unsigned* slot1;    // second copy: the batch after / before the one in slot0
     unsigned* ctl;      // bit 0: slot holding the current batch's state; bits 1..: values used
     int ns;             // streams
     int q, rem;         // nskip = 24*q + rem
 };
 
-// Stream of one thread.  Two delivered batches (48 values) sit in LDS, column `tid`.
-template <int BLOCK>
-struct RlxStream {
-    float* buf;
-    RlxView v;
-    int sid, pos, pos0, nb, cur;
+// Common part: where a stream's persistent state lives.
+struct RlxHome {
+    unsigned* __restrict__ s0;   // this stream's column in slot 0 / slot 1
+    unsigned* __restrict__ s1;
+    unsigned* __restrict__ ctl;
+    int ns, q, rem;
+};
+
+// The stream as the update kernel normally uses it: NB delivered batches (24*NB values) are
+// written to LDS column `tid` when the stream is opened, and the generator state is dead after
+// that -- no registers held, no branch into generator code while the heat-bath runs.  A link
+// update needs 18 values plus 4 per rejected trial; at least 24*(NB-1) are always on hand.  A
+// thread that runs dry reports it (close() < 0) and the kernel repeats that one link with the
+// general stream below, starting from the same persistent state.
+template <int BLOCK, int NB, int NSKIP>
+struct RlxFast {
+    static_assert(NB == 2 || NB == 3, "window of two or three batches");
+    __device__ __forceinline__ void skip(RlxRegs& r) const
+    {
+        if (NSKIP > 0) rlx_skip_static<(NSKIP > 0 ? NSKIP : 24)>(r);
+        else rlx_skip(r, h.q, h.rem);
+    }
+    const float* buf;
+    RlxHome h;
+    int pos, pos0, cur;
+    bool dry;
 
     __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
     {
-        const unsigned* p = v.slot[slot] + sid;
+        const unsigned* __restrict__ p = slot ? h.s1 : h.s0;
 #pragma unroll
-        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * v.ns];
-        r.c = p[(size_t)24 * v.ns];
+        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * h.ns];
+        r.c = p[(size_t)24 * h.ns];
     }
     __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
     {
-        unsigned* p = v.slot[slot] + sid;
+        unsigned* __restrict__ p = slot ? h.s1 : h.s0;
 #pragma unroll
-        for (int w = 0; w < 24; w++) p[(size_t)w * v.ns] = r.s[w];
-        p[(size_t)24 * v.ns] = r.c;
+        for (int w = 0; w < 24; w++) p[(size_t)w * h.ns] = r.s[w];
+        p[(size_t)24 * h.ns] = r.c;
     }
     __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
     {
-        v = view;
-        sid = stream;
+        h.s0 = view.slot0 + stream;
+        h.s1 = view.slot1 + stream;
+        h.ctl = view.ctl + stream;
+        h.ns = view.ns;
+        h.q = view.q;
+        h.rem = view.rem;
         buf = lds_column;
-        const unsigned c = v.ctl[sid];
+        dry = false;
+        const unsigned c = *h.ctl;
         cur = (int)(c & 1u);
         pos = pos0 = (int)(c >> 1);
+#ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
+        return;
+#endif
+        RlxRegs r;
+        load_state(r, cur);
+        rlx_batch(r, lds_column, BLOCK);
+        skip(r);
+        store_state(r, cur ^ 1);
+        rlx_batch(r, lds_column + 24 * BLOCK, BLOCK);
+        if (NB == 3) {
+            skip(r);
+            rlx_batch(r, lds_column + 48 * BLOCK, BLOCK);
+        }
+    }
+    __device__ __forceinline__ float next()
+    {
+        if (pos >= 24 * NB) {
+            dry = true;
+            return 0.5f;
+        }
+#ifdef QCD_ABL_RNG
+        return 0.37f + 0.001f * (float)(pos++ % 24);
+#endif
+        return buf[(pos++) * BLOCK];
+    }
+    __device__ __forceinline__ void draw4(float r[4])
+    {
+        r[0] = next(); r[1] = next(); r[2] = next(); r[3] = next();
+    }
+    __device__ __forceinline__ void draw2(float r[2])
+    {
+        r[0] = next(); r[1] = next();
+    }
+    // number of values used, or -1 when the window ran dry (nothing was made persistent then)
+    __device__ __forceinline__ int close()
+    {
+        if (dry) return -1;
+        int m = pos / 24;
+        if (m > NB - 1) m = NB - 1;
+        if (m == 2) {
+            // rare: the state in front of the third batch was not kept; rebuild it from the one
+            // in front of the second
+            RlxRegs r;
+            load_state(r, cur ^ 1);
+            rlx_round(r);
+            skip(r);
+            store_state(r, cur);
+        }
+        *h.ctl = (unsigned)((cur ^ (m & 1)) | ((pos - 24 * m) << 1));
+        return pos - pos0;
+    }
+};
+
+// The general stream: any number of values, two delivered batches in LDS used as a ring and
+// refilled on demand.  Only threads whose fast window ran dry come here (many rejected trials:
+// small beta), so this path is written for size, not speed.
+template <int BLOCK>
+struct RlxStream {
+    float* buf;
+    unsigned* __restrict__ s0;   // this stream's column in slot 0 / slot 1
+    unsigned* __restrict__ s1;
+    unsigned* __restrict__ ctl;
+    int ns, q, rem;
+    int pos, pos0, nb, cur;
+
+    __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
+    {
+        const unsigned* __restrict__ p = slot ? s1 : s0;
+#pragma unroll
+        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * ns];
+        r.c = p[(size_t)24 * ns];
+    }
+    __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
+    {
+        unsigned* __restrict__ p = slot ? s1 : s0;
+#pragma unroll
+        for (int w = 0; w < 24; w++) p[(size_t)w * ns] = r.s[w];
+        p[(size_t)24 * ns] = r.c;
+    }
+    __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
+    {
+        s0 = view.slot0 + stream;
+        s1 = view.slot1 + stream;
+        ctl = view.ctl + stream;
+        ns = view.ns;
+        q = view.q;
+        rem = view.rem;
+        buf = lds_column;
+        const unsigned c = *ctl;
+        cur = (int)(c & 1u);
+        pos = pos0 = (int)(c >> 1);
+#ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
+        nb = 1000;
+        return;
+#endif
         RlxRegs r;
         load_state(r, cur);
         rlx_batch(r, buf, BLOCK);
-        rlx_skip(r, v.q, v.rem);
+        rlx_skip(r, q, rem);
         store_state(r, cur ^ 1);
         rlx_batch(r, buf + 24 * BLOCK, BLOCK);
         nb = 2;
@@ -76,7 +200,7 @@ struct RlxStream {
         RlxRegs r;
         load_state(r, cur ^ ((nb - 1) & 1));
         rlx_round(r);
-        rlx_skip(r, v.q, v.rem);
+        rlx_skip(r, q, rem);
         store_state(r, cur ^ (nb & 1));
         rlx_batch(r, buf + (nb & 1) * 24 * BLOCK, BLOCK);
         nb++;
@@ -87,6 +211,9 @@ struct RlxStream {
         const int b = pos / 24;
         const int k = pos - 24 * b;
         pos++;
+#ifdef QCD_ABL_RNG
+        return 0.37f + 0.001f * (float)k;
+#endif
         return buf[((b & 1) * 24 + k) * BLOCK];
     }
     __device__ __forceinline__ void draw4(float r[4])
@@ -101,7 +228,7 @@ struct RlxStream {
     {
         int m = pos / 24;
         if (m > nb - 1) m = nb - 1;
-        v.ctl[sid] = (unsigned)((cur ^ (m & 1)) | ((pos - 24 * m) << 1));
+        *ctl = (unsigned)((cur ^ (m & 1)) | ((pos - 24 * m) << 1));
         return pos - pos0;
     }
 };
@@ -125,6 +252,21 @@ struct GidSource {
 // SU(2) heat-bath on a 2x2 block (SU(N)/suncpp/su2/update_su2.cpp:40-126).
 // Returns false when no trial was accepted within nhit (the caller decides what that means:
 // identity inside SU(3), link unchanged for SU(2)).
+//
+// The accept test of a trial is  r3^2 <= 1 - delta/2,  delta = -(ln(1-r0) + cos^2(2 pi r1) ln(1-r2)) / bdet.
+// Lanes of a wavefront need different numbers of trials, so the trial loop runs for the slowest
+// lane; to keep that loop cheap the test is first made with the fp32 hardware transcendentals
+// and decided there unless it falls within a margin that covers their error (then, and only
+// then, the fp64 expression of the reference is evaluated inside the loop).  The fp64 delta of
+// the ACCEPTED trial is computed once after the loop.  Decisions are therefore exactly those of
+// the fp64 test.  Error bounds behind the margin (measured over all 2^24 arguments on gfx950 by
+// tools/fp32_bounds.hip: cos 1.3e-7 absolute, log 1.7e-7 relative) enter with a factor >= 4.
+#define QCD_SCREEN_LOG_REL 1.0e-6f
+#define QCD_SCREEN_COS_ABS 1.0e-6f
+
+// cos(2 pi r), sin(2 pi r) for r in [0, 1): the reference forms 2*pi*r in fp64 and calls cos/sin;
+// cospi/sincospi reduce the argument exactly and are half the instructions
+__device__ __forceinline__ double cos_2pi(float r) { return cospi(2.0 * (double)r); }
 
 template <bool GID, class Rng>
 __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int nhit, Rng& rng, su2& out)
@@ -136,28 +278,56 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int n
 
     const double det = sqrt(Mx * Mx + My * My + Mz * Mz + Mw * Mw);
     const double bdet = beta * det;
+    const double idet = 1.0 / det;
 
     su2 aH;
-    aH.e[0][0] = mk(Mx / det, -My / det);
-    aH.e[0][1] = mk(-Mz / det, -Mw / det);
+    aH.e[0][0] = mk(Mx * idet, -My * idet);
+    aH.e[0][1] = mk(-Mz * idet, -Mw * idet);
     aH.e[1][1] = mk(aH.e[0][0].re, -aH.e[0][0].im);
     aH.e[1][0] = mk(-aH.e[0][1].re, aH.e[0][1].im);
 
     bool flag = false;
     double delta = 0.0;
     float rnd[4];
-    int i = 0;
-    while ((i < nhit) && !flag) {
+    if (GID) {
+        // INTS = 2: the first trial is always accepted (update_su2.cpp:87-90)
         rng.draw4(rnd);
-        const double cosrnd = cos(QCD_PI2 * rnd[1]);
-        if (!GID) {
-            delta = -(log(1.0 - rnd[0]) + cosrnd * cosrnd * log(1.0 - rnd[2])) / bdet;
-            if ((rnd[3] * rnd[3]) <= (1.0 - 0.5 * delta)) flag = true;
-        } else {
-            delta = cosrnd * cosrnd / bdet;
-            flag = true;
+        const double cosrnd = cos_2pi(rnd[1]);
+        delta = cosrnd * cosrnd / bdet;
+        flag = true;
+    } else {
+        const float ibdet32 = (float)(1.0 / bdet);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;  // r0, r1, r2 of the accepted trial
+        int i = 0;
+        while ((i < nhit) && !flag) {
+            rng.draw4(rnd);
+            const float c32 = __builtin_amdgcn_cosf(rnd[1]);
+            const float l0 = __builtin_amdgcn_logf(1.0f - rnd[0]) * 0.6931471805599453f;
+            const float l2 = __builtin_amdgcn_logf(1.0f - rnd[2]) * 0.6931471805599453f;
+            const float d32 = -(l0 + c32 * c32 * l2) * ibdet32;
+            const float r3sq = rnd[3] * rnd[3];
+            const float t32 = 1.0f - 0.5f * d32 - r3sq;
+            const float margin = ibdet32 * (4.0f * QCD_SCREEN_LOG_REL * (fabsf(l0) + fabsf(l2)) +
+                                            4.0f * QCD_SCREEN_COS_ABS * fabsf(l2) + 1.0e-6f) +
+                                 4.0e-6f * fabsf(d32) + 4.0e-6f;
+            bool acc = t32 > margin;
+            if (fabsf(t32) <= margin) {
+                const double cosrnd = cos_2pi(rnd[1]);
+                const double d = -(log(1.0 - rnd[0]) + cosrnd * cosrnd * log(1.0 - rnd[2])) / bdet;
+                acc = (r3sq <= (1.0 - 0.5 * d));
+            }
+            if (acc) {
+                flag = true;
+                a0 = rnd[0];
+                a1 = rnd[1];
+                a2 = rnd[2];
+            }
+            i++;
         }
-        i++;
+        if (flag) {
+            const double cosrnd = cos_2pi(a1);
+            delta = -(log(1.0 - a0) + cosrnd * cosrnd * log(1.0 - a2)) / bdet;
+        }
     }
     if (flag) {
         rng.draw2(rnd);
@@ -165,9 +335,8 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int n
         const double costh = 2.0 * rnd[0] - 1.0;
         const double sinth = sqrt(1.0 - costh * costh);
         const double sinal = sqrt(1.0 - cosal * cosal);
-        const double phi = QCD_PI2 * rnd[1];
-        const double sinphi = sin(phi);
-        const double cosphi = cos(phi);
+        double sinphi, cosphi;
+        sincospi(2.0 * (double)rnd[1], &sinphi, &cosphi);
         su2 c;
         c.e[0][0] = mk(cosal, sinal * costh);
         c.e[0][1] = mk(sinal * sinth * sinphi, sinal * sinth * cosphi);
@@ -204,6 +373,11 @@ __device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, int n
 template <bool GID, class Rng>
 __device__ __forceinline__ void update_link(su3& U, const su3& A, double beta, int nhit, Rng& rng)
 {
+#ifdef QCD_ABL_HB  // diagnostic build: no heat-bath, keeps loads, staple products and the store
+    add_to(U, A);
+    gram_schmidt(U);
+    return;
+#endif
     cm_step<0, 1, GID>(U, A, beta, nhit, rng);
     cm_step<0, 2, GID>(U, A, beta, nhit, rng);
     cm_step<1, 2, GID>(U, A, beta, nhit, rng);
@@ -236,14 +410,22 @@ __device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, cons
             const M m1 = load_site_link<GROUP>(U, g, nu, xmu);
             const M m2 = herm(load_site_link<GROUP>(U, g, DIR, fwd(g, x, nu)));
             const M m3 = herm(load_site_link<GROUP>(U, g, nu, x));
+#ifdef QCD_ABL_STAPLE  // diagnostic build: loads kept, products dropped
+            add_to(stap, m1); add_to(stap, m2); add_to(stap, m3);
+#else
             add_to(stap, mul(mul(m1, m2), m3));
+#endif
         }
         {
             const Site xb = bwd(g, x, nu);
             const M m3 = load_site_link<GROUP>(U, g, nu, xb);
             const M m2 = herm(load_site_link<GROUP>(U, g, DIR, xb));
             const M m1 = herm(load_site_link<GROUP>(U, g, nu, fwd(g, xb, DIR)));
+#ifdef QCD_ABL_STAPLE
+            add_to(stap, m1); add_to(stap, m2); add_to(stap, m3);
+#else
             add_to(stap, mul(mul(m1, m2), m3));
+#endif
         }
     }
     return stap;
@@ -260,17 +442,17 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     return v;  // valid in lane 0 of each wave
 }
 
-template <int GROUP, int DIR, bool GID, int BLOCK>
+template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, const Geom g, const int parity,
                                                   const double beta_eff, const int nhit, const RlxView rv,
                                                   const float* __restrict__ gidr,
                                                   unsigned long long* __restrict__ draws)
 {
-    __shared__ float rbuf[GID ? 1 : 48 * BLOCK];
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    __shared__ float rbuf[GID ? 1 : 24 * RLX_WINDOW * BLOCK];
     unsigned long long used = 0;
-    if (t < g.vh_int) {
-        const Site x = site_of(g, t, parity);
+    Site x;
+    int t;  // stream number = the site pair's half index in the slab
+    if (site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) {
         const int h = half_index(g, x);
         mat<GROUP> A = staple<GROUP, DIR>(U, g, x);
         mat<GROUP> Ul = load_link(U, g, DIR, parity, h, (mat<GROUP>*)nullptr);
@@ -285,10 +467,19 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
             src.accept[1] = gidr[5 * n + lg];
             update_link<true>(Ul, A, beta_eff, nhit, src);
         } else {
-            RlxStream<BLOCK> rs;
+            RlxFast<BLOCK, RLX_WINDOW, NSKIP> rs;
             rs.open(rv, t, rbuf + threadIdx.x);
             update_link<false>(Ul, A, beta_eff, nhit, rs);
-            used = (unsigned long long)rs.close();
+            int n = rs.close();
+            if (n < 0) {
+                // window ran dry: repeat this link from its old value with the general stream
+                Ul = load_link(U, g, DIR, parity, h, (mat<GROUP>*)nullptr);
+                RlxStream<BLOCK> slow;
+                slow.open(rv, t, rbuf + threadIdx.x);
+                update_link<false>(Ul, A, beta_eff, nhit, slow);
+                n = slow.close();
+            }
+            used = (unsigned long long)n;
         }
         store_link(U, g, DIR, parity, h, Ul);
     }

@@ -33,6 +33,14 @@ struct Geom {
     int vh_alloc;        // stored half-sites = (nx + 2*halo)*slice_h
     int gsites;          // sites of the FULL lattice
     int gslice;          // sites per x slice = ny*nz*nt
+    // update-pass work distribution over the 8 XCDs (each has its own 4 MiB L2): the (z,t)
+    // plane is cut into nzr x ntr = 8 regions (or 1 = no cut); workgroup b works for region
+    // b % 8 and walks that region's half-sites with x slowest, so that the workgroups an XCD
+    // runs at one time cover a few consecutive x-slices of ONE (z,t) box and find their
+    // +-y, +-z, +-t and +-x neighbours in that XCD's L2
+    int nzr, ntr;        // regions along z and t
+    int rz, rt;          // z and t extent of a region
+    int region_h;        // half-sites of a region per x slice = nyh*rz*rt
 };
 
 struct Site {
@@ -67,6 +75,31 @@ __device__ __forceinline__ Site site_of(const Geom& g, int t, int par)
     s.y = 2 * yh + yb;
     return s;
 }
+// site of parity `par` handled by thread `tid` of workgroup `b` in an update pass; false if
+// the thread has no site.  *stream is the site pair's half index inside the owned slab
+// (the reference's thread index, SU(N)/suncpp/coord_work/coord_work.cpp:151-175).
+template <int BLOCK>
+__device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid, int par, Site& s, int& stream)
+{
+    const int regions = g.nzr * g.ntr;
+    const int k = b % regions;
+    const int w = (b / regions) * BLOCK + tid;
+    if (w >= g.nx * g.region_h) return false;
+    s.xs = w / g.region_h;
+    int q = w - s.xs * g.region_h;
+    const int plane = g.nyh * g.rz;
+    const int tl = q / plane;
+    q -= tl * plane;
+    const int zl = q / g.nyh;
+    const int yh = q - zl * g.nyh;
+    s.z = (k % g.nzr) * g.rz + zl;
+    s.t = (k / g.nzr) * g.rt + tl;
+    const int yb = (par + g.x0 + s.xs + s.z + s.t) & 1;
+    s.y = 2 * yh + yb;
+    stream = ((s.xs * g.nt + s.t) * g.nz + s.z) * g.nyh + yh;
+    return true;
+}
+
 // nearest neighbours with periodic wrap (coord_work.cpp:63-149); in a slab the x direction
 // does not wrap: the halo slices stand in for the neighbouring contexts
 __device__ __forceinline__ Site fwd(const Geom& g, Site s, int dir)

@@ -70,31 +70,67 @@ __host__ __device__ __forceinline__ void rlx_step_rotate(RlxRegs& r)
     r.s[0] = top;
 }
 
-// skip nskip = 24*q + rem values
+// skip nskip = 24*q + rem values (any luxury level)
 __host__ __device__ __forceinline__ void rlx_skip(RlxRegs& r, int q, int rem)
 {
     for (int n = 0; n < q; n++) rlx_round(r);
     for (int n = 0; n < rem; n++) rlx_step_rotate(r);
 }
 
-// deliver one batch: 24 steps, value k written to out[k * stride]; includes the reference's
-// fix-up of tiny values (random.cpp:566-570), done in fp32 exactly as there
+// the same for a skip count known at compile time: the closing rotation by REM words is a
+// renaming of registers, not a copy
+template <int NSKIP>
+__host__ __device__ __forceinline__ void rlx_skip_static(RlxRegs& r)
+{
+    constexpr int Q = NSKIP / 24, REM = NSKIP % 24;
+    for (int n = 0; n < Q; n++) rlx_round(r);
+#pragma unroll
+    for (int k = 0; k < REM; k++) {
+        const int i = 23 - k;
+        const int j = (i + 10) % 24;
+        QCD_RLX_STEP(r, i, j);
+    }
+    if (REM) {
+        RlxRegs t = r;
+#pragma unroll
+        for (int k = 0; k < 24; k++) r.s[k] = t.s[(k + 24 - REM) % 24];
+    }
+}
+
+// deliver one batch: 24 steps, value k written to out[k * stride] as the float k' * 2^-24.
+// The reference adds a correction to values below 2^-12 (random.cpp:566-570: the value plus
+// 2^-24 times the word its j24 index points at after the step, in fp32); one value in 4096
+// needs it, so the batch is produced without it and patched afterwards when its smallest value
+// says so.  The word the correction reads is, for the first nine values of a batch, a word of
+// the state in front of the batch (kept in `pre`), later one of the values already delivered.
 template <typename OutT>
 __host__ __device__ __forceinline__ void rlx_batch(RlxRegs& r, OutT* out, int stride)
 {
+    unsigned pre[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) pre[k] = r.s[k];
+    unsigned lo = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < 24; k++) {
         const int i = 23 - k;
         const int j = (i + 10) % 24;
         QCD_RLX_STEP(r, i, j);
-        const int jn = (i + 9) % 24;  // the reference's j24 after its decrement
         const unsigned ui = r.s[i];
-        float uni = (float)ui * RLX_TWOM24;
-        if (ui < 4096u) {
-            uni = uni + RLX_TWOM24 * ((float)r.s[jn] * RLX_TWOM24);
-            if (uni == 0.0f) uni = RLX_TWOM24 * RLX_TWOM24;
+        lo = ui < lo ? ui : lo;
+        out[k * stride] = (float)ui * RLX_TWOM24;
+    }
+    if (lo < 4096u) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) {
+            const unsigned ui = r.s[23 - k];
+            if (ui < 4096u) {
+                const unsigned sj = (k <= 8) ? pre[k <= 8 ? 8 - k : 0] : r.s[(32 - k) % 24];
+                float uni = (float)ui * RLX_TWOM24;
+                uni = uni + RLX_TWOM24 * ((float)sj * RLX_TWOM24);
+                if (uni == 0.0f) uni = RLX_TWOM24 * RLX_TWOM24;
+                out[k * stride] = uni;
+            }
         }
-        out[k * stride] = uni;
     }
 }
 

@@ -149,18 +149,21 @@ __device__ __forceinline__ void gram_schmidt(su3& a)
     cplx v1 = a.e[1][0], v2 = a.e[1][1], v3 = a.e[1][2];
     const double norm_u = sqrt(u1.re * u1.re + u2.re * u2.re + u3.re * u3.re + u1.im * u1.im +
                                u2.im * u2.im + u3.im * u3.im);
-    u1 = mk(u1.re / norm_u, u1.im / norm_u);
-    u2 = mk(u2.re / norm_u, u2.im / norm_u);
-    u3 = mk(u3.re / norm_u, u3.im / norm_u);
+    // one reciprocal and six products instead of the reference's six quotients (<= 1 ulp apart)
+    const double iu = 1.0 / norm_u;
+    u1 = mk(u1.re * iu, u1.im * iu);
+    u2 = mk(u2.re * iu, u2.im * iu);
+    u3 = mk(u3.re * iu, u3.im * iu);
     const cplx sp = cadd(cadd(cmul(v1, conj(u1)), cmul(v2, conj(u2))), cmul(v3, conj(u3)));
     v1 = csub(v1, cmul(u1, sp));
     v2 = csub(v2, cmul(u2, sp));
     v3 = csub(v3, cmul(u3, sp));
     const double norm_v = sqrt(v1.re * v1.re + v2.re * v2.re + v3.re * v3.re + v1.im * v1.im +
                                v2.im * v2.im + v3.im * v3.im);
-    v1 = mk(v1.re / norm_v, v1.im / norm_v);
-    v2 = mk(v2.re / norm_v, v2.im / norm_v);
-    v3 = mk(v3.re / norm_v, v3.im / norm_v);
+    const double iv = 1.0 / norm_v;
+    v1 = mk(v1.re * iv, v1.im * iv);
+    v2 = mk(v2.re * iv, v2.im * iv);
+    v3 = mk(v3.re * iv, v3.im * iv);
     a.e[0][0] = u1; a.e[0][1] = u2; a.e[0][2] = u3;
     a.e[1][0] = v1; a.e[1][1] = v2; a.e[1][2] = v3;
     reconstruct(a);
