@@ -73,8 +73,10 @@ void qcd_destroy(qcd_ctx *ctx);
 /* message of the last failing call on this thread */
 const char *qcd_last_error(void);
 
-/* use a caller-owned hipStream_t (passed as void*) for all subsequent work; NULL = own stream */
+/* use a caller-owned hipStream_t (passed as void*) for all subsequent work; NULL is the device's
+ * default stream.  qcd_reset_stream goes back to the context's own (non-blocking) stream. */
 int qcd_set_stream(qcd_ctx *ctx, void *hip_stream);
+int qcd_reset_stream(qcd_ctx *ctx);
 int qcd_synchronize(qcd_ctx *ctx);
 
 /* kernel_run(sun_init_id) (suncl.cpp:5243-5252; kernels lattice_init_cold / lattice_init_gid,
@@ -125,6 +127,15 @@ int qcd_download(qcd_ctx *ctx, void *host_table, size_t bytes, int rowsize);
 size_t qcd_halo_bytes(const qcd_ctx *ctx);
 int    qcd_halo_pack(qcd_ctx *ctx, int side, int dir, int parity, void *dev_buf);
 int    qcd_halo_unpack(qcd_ctx *ctx, int side, int dir, int parity, const void *dev_buf);
+
+/* UpdateEdges between two parts that live in ONE process (the reference's own single-process
+ * BigLattice, suncl.cpp:4005-4061): boundary slice `pack_side` of src -> halo `recv_side` of dst,
+ * same device or peer device; ordered after src's and before dst's later work. */
+int    qcd_halo_copy(qcd_ctx *src, int pack_side, qcd_ctx *dst, int recv_side, int dir, int parity);
+
+/* device_select / device_initialize (clinterface.cpp:345-459): what the host needs to know */
+int qcd_device_count(int *count);
+int qcd_device_name(int device, char *buf, size_t buflen);
 
 /* GPU_debug.profiling + print_time_detailed (clinterface.cpp:1254-1266, 1626-1667) */
 int qcd_set_profiling(qcd_ctx *ctx, int on);

@@ -13,6 +13,27 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
          "-Xarch_host", "-ffp-contract=off"]
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_BIN = os.path.join(HERE, "bin", "qcdgpu")
+HOST_SOURCES = ["model.cpp", "qcdgpu_main.cpp"]
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host shell (run API + program entry) above the C-ABI."""
+    srcs = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, "model.h"), LIB]
+    if (not force and os.path.exists(HOST_BIN)
+            and all(os.path.getmtime(d) <= os.path.getmtime(HOST_BIN) for d in deps)):
+        return HOST_BIN
+    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall"] + srcs + ["-o", HOST_BIN, "-L" + os.path.dirname(LIB),
+           "-lqcdgpu_amd", "-Wl,-rpath,$ORIGIN/../lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return HOST_BIN
+
+
 def up_to_date():
     if not os.path.exists(LIB):
         return False
@@ -22,6 +43,7 @@ def up_to_date():
 
 def build(force=False, verbose=False):
     if not force and up_to_date():
+        build_host(force, verbose)
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -29,6 +51,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    build_host(force, verbose)
     return LIB
 
 

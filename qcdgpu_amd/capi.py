@@ -34,15 +34,25 @@ class Timing(C.Structure):
 
 
 # every symbol include/qcdgpu_amd.h declares
-EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd_synchronize",
+EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd_reset_stream",
+           "qcd_synchronize",
            "qcd_init_lattice", "qcd_update", "qcd_sweep", "qcd_reunitarize",
            "qcd_measure_plaquette", "qcd_measure_action", "qcd_measure_polyakov",
            "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums", "qcd_upload", "qcd_download",
-           "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_set_profiling",
+           "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_halo_copy",
+           "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws"]
 
 
 def _load():
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  A process must end up with ONE copy:
+    # when torch is importable it is imported first, so that this library binds to the runtime
+    # torch has already loaded (torch initialised after a second runtime sees no GPUs).
+    if not os.environ.get("QCDGPU_AMD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc --offload-arch=gfx950)" % LIB_PATH)
@@ -54,6 +64,7 @@ def _load():
     lib.qcd_destroy.restype = None
     lib.qcd_last_error.restype = C.c_char_p
     lib.qcd_set_stream.argtypes = [P, P]
+    lib.qcd_reset_stream.argtypes = [P]
     lib.qcd_synchronize.argtypes = [P]
     lib.qcd_init_lattice.argtypes = [P]
     lib.qcd_update.argtypes = [P, I, I]
@@ -68,6 +79,9 @@ def _load():
     lib.qcd_halo_bytes.restype = C.c_size_t
     lib.qcd_halo_pack.argtypes = [P, I, I, I, P]
     lib.qcd_halo_unpack.argtypes = [P, I, I, I, P]
+    lib.qcd_halo_copy.argtypes = [P, I, P, I, I, I]
+    lib.qcd_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.qcd_device_name.argtypes = [I, C.c_char_p, C.c_size_t]
     lib.qcd_set_profiling.argtypes = [P, I]
     lib.qcd_get_timing.argtypes = [P, C.POINTER(Timing)]
     lib.qcd_timed_sweeps.argtypes = [P, I, pd, C.POINTER(C.c_ulonglong)]
@@ -181,6 +195,9 @@ class Context:
 
     def halo_unpack(self, side, direction, parity, dev_ptr):
         _check(lib.qcd_halo_unpack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
+
+    def halo_copy_to(self, pack_side, dst, recv_side, direction, parity):
+        _check(lib.qcd_halo_copy(self.h, pack_side, dst.h, recv_side, direction, parity))
 
     def set_profiling(self, on):
         _check(lib.qcd_set_profiling(self.h, int(on)))

@@ -53,6 +53,8 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 struct qcd_ctx {
     qcd_params p;
+    double2* edge_buf;        // message buffer of qcd_halo_copy (lazily allocated)
+    hipEvent_t edge_ev;
     Geom g;
     int ncomp;
     hipStream_t own_stream, stream;
@@ -402,6 +404,8 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipFree(c->rv.slot1);
     (void)hipFree(c->rv.ctl);
     (void)hipFree(c->gidr);
+    (void)hipFree(c->edge_buf);
+    if (c->edge_ev) (void)hipEventDestroy(c->edge_ev);
     (void)hipFree(c->partial);
     (void)hipFree(c->result_dev);
     (void)hipFree(c->draws_dev);
@@ -418,7 +422,16 @@ int qcd_set_stream(qcd_ctx* c, void* hip_stream)
     int rc = check_ctx(c, false);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;  // NULL is the device's default stream
+    return QCD_OK;
+}
+
+int qcd_reset_stream(qcd_ctx* c)
+{
+    int rc = check_ctx(c, false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return QCD_OK;
 }
 
@@ -648,6 +661,60 @@ int qcd_halo_pack(qcd_ctx* c, int side, int dir, int parity, void* dev_buf)
 int qcd_halo_unpack(qcd_ctx* c, int side, int dir, int parity, const void* dev_buf)
 {
     return halo_op(c, side, dir, parity, const_cast<void*>(dev_buf), false);
+}
+
+static int edge_buffers(qcd_ctx* c)
+{
+    if (c->edge_buf) return QCD_OK;
+    const size_t bytes = qcd_halo_bytes(c);
+    HIP_TRY(hipMalloc(&c->edge_buf, 2 * bytes));  // [0, bytes): outgoing, [bytes, 2*bytes): incoming
+    HIP_TRY(hipEventCreateWithFlags(&c->edge_ev, hipEventDisableTiming));
+    return QCD_OK;
+}
+
+int qcd_halo_copy(qcd_ctx* src, int pack_side, qcd_ctx* dst, int recv_side, int dir, int parity)
+{
+    if (!src || !dst) return fail(QCD_ERR_INVALID, "null context");
+    if (qcd_halo_bytes(src) != qcd_halo_bytes(dst) || src->p.group != dst->p.group)
+        return fail(QCD_ERR_INVALID, "parts with different slice shapes");
+    const size_t bytes = qcd_halo_bytes(src);
+    int rc = check_ctx(src, true);
+    if (rc) return rc;
+    if ((rc = edge_buffers(src))) return rc;
+    if ((rc = qcd_halo_pack(src, pack_side, dir, parity, src->edge_buf))) return rc;
+    HIP_TRY(hipEventRecord(src->edge_ev, src->stream));
+
+    if ((rc = check_ctx(dst, true))) return rc;
+    if ((rc = edge_buffers(dst))) return rc;
+    HIP_TRY(hipStreamWaitEvent(dst->stream, src->edge_ev, 0));
+    const double2* from = src->edge_buf;
+    if (src->p.device != dst->p.device) {
+        double2* in = dst->edge_buf + bytes / sizeof(double2);
+        HIP_TRY(hipMemcpyPeerAsync(in, dst->p.device, src->edge_buf, src->p.device, bytes, dst->stream));
+        from = in;
+    }
+    if ((rc = qcd_halo_unpack(dst, recv_side, dir, parity, from))) return rc;
+    // the sender must not repack its outgoing buffer before the receiver has consumed it
+    HIP_TRY(hipEventRecord(dst->edge_ev, dst->stream));
+    HIP_TRY(hipSetDevice(src->p.device));
+    HIP_TRY(hipStreamWaitEvent(src->stream, dst->edge_ev, 0));
+    return QCD_OK;
+}
+
+int qcd_device_count(int* count)
+{
+    if (!count) return fail(QCD_ERR_INVALID, "null output");
+    HIP_TRY(hipGetDeviceCount(count));
+    return QCD_OK;
+}
+
+int qcd_device_name(int device, char* buf, size_t buflen)
+{
+    if (!buf || buflen == 0) return fail(QCD_ERR_INVALID, "null output");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s)", prop.name, prop.gcnArchName);
+    return QCD_OK;
 }
 
 int qcd_set_profiling(qcd_ctx* c, int on)

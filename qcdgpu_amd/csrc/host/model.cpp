@@ -1,0 +1,499 @@
+// model.cpp -- host-side run API over the C-ABI (see model.h).
+#include "model.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace model_HIP {
+
+// ---------------------------------------------------------------------------------------------
+// init.dat tokenizer: "KEY = value" per line, leading blanks and tabs skipped, text after '#'
+// ignored, the value read as int, as double and as raw text; "{a, b, ...}" integer vectors for
+// the BigLattice keys (SU(N)/clinterface/clinterface.cpp:2060-2154, SU(N)/suncpp/IO/io.cpp:42-116)
+
+std::vector<init_parameter> get_init_file(const char* finitf)
+{
+    std::vector<init_parameter> result;
+    FILE* stream = fopen(finitf, "r");
+    if (!stream) return result;
+    char line[250];
+    while (fgets(line, sizeof(line), stream) != NULL) {
+        const size_t len = strlen(line);
+        const size_t eq = strcspn(line, "=");
+        if (eq >= len) continue;  // no '=': not a parameter line
+        size_t s1 = 0;
+        while (line[s1] == ' ' || line[s1] == '\t') s1++;
+        long e1 = (long)eq - 1;
+        while (e1 >= 0 && (line[e1] == ' ' || line[e1] == '\t')) e1--;
+        init_parameter p;
+        if (e1 >= (long)s1) p.Variable.assign(line + s1, (size_t)(e1 - (long)s1 + 1));
+        long fin = (long)strcspn(line, "#") - 1;
+        while (fin >= 0 && (line[fin] == ' ' || line[fin] == '\t' || line[fin] == '\n' || line[fin] == '\r')) fin--;
+        size_t s3 = eq + 1;
+        while (line[s3] == ' ' || line[s3] == '\t') s3++;
+        if (fin >= (long)s3) p.txtVarVal.assign(line + s3, (size_t)(fin - (long)s3 + 1));
+        sscanf(p.txtVarVal.c_str(), "%d", &p.iVarVal);
+        sscanf(p.txtVarVal.c_str(), "%lf", &p.fVarVal);
+        if (!p.txtVarVal.empty() && p.txtVarVal[0] == '{') {
+            const char* t = p.txtVarVal.c_str() + 1;
+            int v, n;
+            while (sscanf(t, " %d%n", &v, &n) == 1) {
+                p.ivVarVal.push_back(v);
+                t += n;
+                while (*t == ' ' || *t == ',') t++;
+            }
+        }
+        result.push_back(p);
+    }
+    fclose(stream);
+    return result;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PRNG (SU(N)/random/random.cpp:140-172)
+
+void PRNG::parameters_setup(const char* parameter, int ivalue, const char* text_value)
+{
+    if (!strcmp(parameter, "RANDSERIES")) PRNG_randseries = (unsigned)ivalue;
+    if (!strcmp(parameter, "PRNG")) {
+        if (!strcmp(text_value, "RANLUX0")) PRNG_generator = PRNG_generator_RANLUX0;
+        if (!strcmp(text_value, "RANLUX1")) PRNG_generator = PRNG_generator_RANLUX1;
+        if (!strcmp(text_value, "RANLUX2")) PRNG_generator = PRNG_generator_RANLUX2;
+        if (!strcmp(text_value, "RANLUX3")) PRNG_generator = PRNG_generator_RANLUX3;
+        if (!strcmp(text_value, "RANLUX4")) PRNG_generator = PRNG_generator_RANLUX4;
+        // the reference's other generators are not compiled into its kernels either
+        // (SU(N)/random/random.cl:5-12); RANLUX3 stays selected for them
+    }
+}
+
+int PRNG::print_generator(char* header, int header_size) const
+{
+    int j = 0;
+    j += snprintf(header + j, header_size - j, " random series               : %u\n", PRNG_srandtime);
+    j += snprintf(header + j, header_size - j, " PRN generator               : RANLUX%d\n", (int)PRNG_generator);
+    return j;
+}
+
+// SU(N)/data_analysis/data_analysis.cpp:107-135: sample 0 (the initial configuration) is excluded
+void lattice_data_analysis(data_analysis* d)
+{
+    const int last_index = (int)d->data.size() - 1;
+    d->mean_value = 0.0;
+    d->variance = 0.0;
+    if (last_index < 0) return;
+    for (int i = 1; i <= last_index; i++) d->mean_value += d->data[i];
+    if (last_index > 0) d->mean_value /= (double)last_index;
+    for (int i = 1; i <= last_index; i++) d->variance += pow(d->data[i] - d->mean_value, 2);
+    if (last_index > 0) d->variance /= (double)last_index;
+    d->GPU_last_value = d->data[last_index];
+}
+
+// ---------------------------------------------------------------------------------------------
+
+model::model()
+{
+    PRNG0 = new PRNG();
+    // defaults of main() (SU(N)/QCDGPU.cpp:98-220)
+    PRNG0->PRNG_generator = PRNG::PRNG_generator_RANLUX3;
+    PRNG0->PRNG_randseries = 54;
+    static const char* names[DM_max + 1] = {"Wilson_loop", "S_total", "Plq_total", "S_spat", "S_temp",
+                                            "Plq_spat", "Plq_temp", "Polyakov_loop", "Polyakov_loop_im",
+                                            "Polyakov_loop_P2", "Polyakov_loop_P4"};
+    for (int i = 0; i <= DM_max; i++) Analysis[i].data_name = names[i];
+}
+
+model::~model()
+{
+    for (auto& s : SubLat) qcd_destroy(s.ctx);
+    delete PRNG0;
+    free(timestart);
+    free(timeend);
+}
+
+void model::check(int rc, const char* what)
+{
+    if (rc != QCD_OK) throw model_error(std::string(what) + ": " + qcd_last_error());
+}
+
+// key table of SU(N)/suncl/suncl.cpp:305-459 (the keys of observables this engine does not
+// measure are accepted and ignored, like unknown keys are in the reference)
+void model::lattice_get_init_file(char* file)
+{
+    std::vector<init_parameter> parameters = get_init_file(file);
+    std::vector<int> n1, devices, rnds;
+    for (const init_parameter& p : parameters) {
+        const char* v = p.Variable.c_str();
+        if (!strcmp(v, "PLATFORM")) desired_platform = p.iVarVal;
+        if (!strcmp(v, "DEVICE")) {
+            if (!p.ivVarVal.empty()) devices = p.ivVarVal;
+            else desired_device = p.iVarVal;
+            device_select = true;
+        }
+        if (!strcmp(v, "GROUP")) {
+            lattice_group = p.iVarVal;
+            char buf[16];
+            snprintf(buf, sizeof(buf), "su%i-", lattice_group);
+            fprefix = buf;
+        }
+        if (!strcmp(v, "ND")) lattice_nd = p.iVarVal;
+        if (!strcmp(v, "L1")) lattice_full_size[0] = lattice_domain_size[0] = p.iVarVal;
+        if (!strcmp(v, "L2")) lattice_full_size[1] = lattice_domain_size[1] = p.iVarVal;
+        if (!strcmp(v, "L3")) lattice_full_size[2] = lattice_domain_size[2] = p.iVarVal;
+        if (!strcmp(v, "L4")) lattice_full_size[3] = lattice_domain_size[3] = p.iVarVal;
+        if (!strcmp(v, "LS"))
+            for (int i = 0; i < 3; i++) lattice_full_size[i] = lattice_domain_size[i] = p.iVarVal;
+        if (!strcmp(v, "LT") && lattice_nd >= 1 && lattice_nd <= 4)  // ND must precede LT, as in the reference
+            lattice_full_size[lattice_nd - 1] = lattice_domain_size[lattice_nd - 1] = p.iVarVal;
+        if (!strcmp(v, "N1") && !p.ivVarVal.empty()) n1 = p.ivVarVal;
+        if (!strcmp(v, "ITER")) ITER = p.iVarVal;
+        if (!strcmp(v, "NITER")) NITER = p.iVarVal;
+        if (!strcmp(v, "NHIT")) NHIT = p.iVarVal;
+        if (!strcmp(v, "BETA")) BETA = p.fVarVal;
+        if (!strcmp(v, "PHI")) PHI = p.fVarVal;
+        if (!strcmp(v, "OMEGA")) OMEGA = p.fVarVal;
+        if (!strcmp(v, "NAV")) NAV = p.iVarVal;
+        if (!strcmp(v, "INTS"))
+            ints = (p.iVarVal == 0) ? model_start_hot : (p.iVarVal == 2 ? model_start_gid : model_start_cold);
+        if (!strcmp(v, "RANDSERIES") && !p.ivVarVal.empty()) rnds = p.ivVarVal;
+        PRNG0->parameters_setup(v, p.ivVarVal.empty() ? p.iVarVal : p.ivVarVal[0], p.txtVarVal.c_str());
+        if (!strcmp(v, "OUTPUTPATH")) path = p.txtVarVal;
+        if (!strcmp(v, "FINISHPATH")) finishpath = p.txtVarVal;
+        if (!strcmp(v, "GETWILSON")) get_wilson_loop = true;
+        if (!strcmp(v, "GETRETRACE")) get_plaquettes_avr = true;
+        if (!strcmp(v, "PL_LEVEL")) PL_level = p.iVarVal;
+        if (!strcmp(v, "WILSONR")) wilson_R = p.iVarVal;
+        if (!strcmp(v, "WILSONT")) wilson_T = p.iVarVal;
+    }
+    if (n1.size() > 1) {
+        lattice_Nparts = (int)n1.size();
+        SubLat.assign(n1.size(), SubLattice());
+        for (size_t k = 0; k < n1.size(); k++) {
+            SubLat[k].Nx = n1[k];
+            SubLat[k].Ny = lattice_full_size[1];
+            SubLat[k].Nz = lattice_full_size[2];
+            SubLat[k].Nt = lattice_full_size[3];
+            SubLat[k].desired_device = k < devices.size() ? devices[k] : desired_device;
+        }
+    } else if (!devices.empty()) {
+        desired_device = devices[0];
+    }
+}
+
+const char* model::lattice_make_header(void)
+{
+    // SU(N)/suncl/suncl.cpp:468-578
+    char buf[16384];
+    int j = 0;
+    const int n = (int)sizeof(buf);
+    j += snprintf(buf + j, n - j, " GPU SU(%u) simulator %s (QCDGPU-m-Nx-8.1)\n\n", lattice_group, version.c_str());
+    j += snprintf(buf + j, n - j, " Monte Carlo simulation of %uD SU(%u) LGT\n\n", lattice_nd, lattice_group);
+    j += snprintf(buf + j, n - j, " ***************************************************\n");
+    if (lattice_Nparts > 1) {
+        for (int k = 0; k < lattice_Nparts; k++) {
+            char name[256] = "?";
+            qcd_device_name(SubLat[k].desired_device, name, sizeof(name));
+            j += snprintf(buf + j, n - j, " Part %i:                     \n", k + 1);
+            j += snprintf(buf + j, n - j, "    Active OpenCL platform   : %s\n", "AMD HIP (ROCm)");
+            j += snprintf(buf + j, n - j, "    Active OpenCL device     : %s\n", name);
+        }
+    } else {
+        char name[256] = "?";
+        qcd_device_name(desired_device, name, sizeof(name));
+        j += snprintf(buf + j, n - j, " Active OpenCL platform   : %s\n", "AMD HIP (ROCm)");
+        j += snprintf(buf + j, n - j, " Active OpenCL device     : %s\n", name);
+    }
+    j += snprintf(buf + j, n - j, " ***************************************************\n");
+    j += snprintf(buf + j, n - j, " lattice size                : %3u x %3u x %3u x %3u\n", lattice_full_size[0],
+                  lattice_full_size[1], lattice_full_size[2], lattice_full_size[3]);
+    if (lattice_Nparts > 1) {
+        j += snprintf(buf + j, n - j, " ---------------------------------------------------\n");
+        for (int k = 0; k < lattice_Nparts; k++)
+            j += snprintf(buf + j, n - j, " Part %i                      : %3u x %3u x %3u x %3u\n", k + 1, SubLat[k].Nx,
+                          SubLat[k].Ny, SubLat[k].Nz, SubLat[k].Nt);
+        j += snprintf(buf + j, n - j, " ---------------------------------------------------\n");
+    }
+    j += snprintf(buf + j, n - j, " init                        : %i\n", INIT);
+    j += snprintf(buf + j, n - j, " ints (0=hot, 1=cold, 2=gid) : %i\n",
+                  ints == model_start_hot ? 0 : (ints == model_start_cold ? 1 : 2));
+    j += PRNG0->print_generator(buf + j, n - j);
+    j += snprintf(buf + j, n - j, " nav                         : %i\n", NAV);
+    j += snprintf(buf + j, n - j, " niter                       : %i\n", NITER);
+    j += snprintf(buf + j, n - j, " iter (# of samples)         : %i\n", ITER);
+    j += snprintf(buf + j, n - j, " nhit                        : %i\n", NHIT);
+    j += snprintf(buf + j, n - j, " nhitPar                     : %i\n", NHITPar);
+    if (precision == model_precision_single) j += snprintf(buf + j, n - j, " precision                   : single\n");
+    if (precision == model_precision_mixed) j += snprintf(buf + j, n - j, " precision                   : mixed\n");
+    if (precision == model_precision_double) j += snprintf(buf + j, n - j, " precision                   : double\n");
+    j += snprintf(buf + j, n - j, " ***************************************************\n");
+    // model_make_header, SU(N)/suncl/suncl.cpp:779-795
+    j += snprintf(buf + j, n - j, " Wilson loop R               : %i\n", wilson_R);
+    j += snprintf(buf + j, n - j, " Wilson loop T               : %i\n", wilson_T);
+    j += snprintf(buf + j, n - j, " BETA                        : %16.13e\n", BETA);
+    j += snprintf(buf + j, n - j, " PHI   (lambda_3)            : %16.13e\n", PHI);
+    j += snprintf(buf + j, n - j, " OMEGA (lambda_8)            : %16.13e\n", OMEGA);
+    j += snprintf(buf + j, n - j, " ***************************************************\n");
+    header = buf;
+    return header.c_str();
+}
+
+static char* current_datetime(time_t* t)
+{
+    time(t);
+    char* result = (char*)calloc(256, sizeof(char));
+    snprintf(result, 256, "%s", ctime(t));
+    return result;
+}
+
+// lattice_init (SU(N)/suncl/suncl.cpp:618-706): device selection and buffers; one context per part
+void model::lattice_init(void)
+{
+    if (lattice_nd != 4) throw model_error("ND must be 4");
+    if (precision != model_precision_double) throw model_error("only double precision is implemented");
+    if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
+    // initialize_CPU (SU(N)/random/random.cpp:174-182): RANDSERIES = 0 means "seed from the clock"
+    PRNG0->PRNG_srandtime = (unsigned int)time(NULL);
+    if (!PRNG0->PRNG_randseries) PRNG0->PRNG_randseries = PRNG0->PRNG_srandtime;
+    else PRNG0->PRNG_srandtime = PRNG0->PRNG_randseries;
+
+    if (lattice_Nparts <= 1) {
+        lattice_Nparts = 1;
+        SubLat.assign(1, SubLattice());
+        SubLat[0].Nx = lattice_full_size[0];
+        SubLat[0].Ny = lattice_full_size[1];
+        SubLat[0].Nz = lattice_full_size[2];
+        SubLat[0].Nt = lattice_full_size[3];
+        SubLat[0].desired_device = desired_device;
+    }
+    int total = 0;
+    for (auto& s : SubLat) total += s.Nx;
+    if (total != lattice_full_size[0]) throw model_error("N1 = {..} does not add up to L1");
+
+    int x0 = 0;
+    for (auto& s : SubLat) {
+        qcd_params p;
+        memset(&p, 0, sizeof(p));
+        p.group = lattice_group;
+        p.nd = lattice_nd;
+        for (int i = 0; i < 4; i++) p.L[i] = lattice_full_size[i];
+        p.precision = 2;
+        p.beta = BETA;
+        p.nhit = NHIT;
+        p.start_mode = (ints == model_start_hot) ? QCD_START_HOT : (ints == model_start_gid ? QCD_START_GID : QCD_START_COLD);
+        p.lux_level = PRNG0->lux_level();
+        p.rand_series = PRNG0->PRNG_randseries;
+        p.device = s.desired_device;
+        p.x0 = x0;
+        p.nx_local = s.Nx;
+        p.halo = lattice_Nparts > 1 ? 1 : 0;
+        check(qcd_create(&s.ctx, &p), "qcd_create");
+        check(qcd_set_profiling(s.ctx, profiling ? 1 : 0), "qcd_set_profiling");
+        x0 += s.Nx;
+    }
+    lattice_make_header();
+}
+
+void model::UpdateEdges(int dir, int parity)
+{
+    if (lattice_Nparts < 2) return;
+    for (int k = 0; k < lattice_Nparts; k++) {
+        const int k_next = (k + 1) % lattice_Nparts;
+        // last owned slice of part k -> left halo of part k+1 (every direction)
+        check(qcd_halo_copy(SubLat[k].ctx, 1, SubLat[k_next].ctx, 0, dir, parity), "UpdateEdges");
+        // first owned slice of part k+1 -> right halo of part k (nothing reads U_x there)
+        if (dir != 0) check(qcd_halo_copy(SubLat[k_next].ctx, 0, SubLat[k].ctx, 1, dir, parity), "UpdateEdges");
+    }
+}
+
+// one sweep in the reference order: odd X,Y,Z,T then even X,Y,Z,T, edges after every pass
+// (SU(N)/suncl/suncl.cpp:5357-5377 and :5026-5138); re-unitarisation is part of the update kernel
+void model::sweep(void)
+{
+    if (turnoff_updates) return;
+    for (int parity = 1; parity >= 0; parity--)
+        for (int dir = 0; dir < 4; dir++) {
+            for (auto& s : SubLat) check(qcd_update(s.ctx, parity, dir), "qcd_update");
+            UpdateEdges(dir, parity);
+        }
+}
+
+void model::measure(int index)
+{
+    double plq[2] = {0, 0}, pl[4] = {0, 0, 0, 0};
+    for (auto& s : SubLat) {
+        double a[2], b[4];
+        if (get_plaquettes_avr || get_actions_avr) {
+            check(qcd_measure_plaquette_sums(s.ctx, a), "qcd_measure_plaquette_sums");
+            plq[0] += a[0];
+            plq[1] += a[1];
+        }
+        if (PL_level > 0) {
+            check(qcd_measure_polyakov_sums(s.ctx, b), "qcd_measure_polyakov_sums");
+            for (int i = 0; i < 4; i++) pl[i] += b[i];
+        }
+    }
+    const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
+    const double n3 = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2];
+    const double g = lattice_group;
+    // SU(N)/suncpp/Measurements/Plq.h:90-92, S.h:92-97
+    const double p3[3] = {plq[0] / (3 * v), plq[1] / (3 * v), (plq[0] + plq[1]) / (6 * v)};
+    for (int i = 0; i < 3; i++) {
+        plq_[i][index] = p3[i];
+        act_[i][index] = BETA * (1 - p3[i] / g);
+    }
+    // SU(N)/suncl/su3cpu.cpp:1427-1430
+    pl_[0][index] = pl[0] / (n3 * g);
+    pl_[1][index] = pl[1] / (n3 * g);
+    pl_[2][index] = pl[2] / (n3 * g * g);
+    pl_[3][index] = pl[3] / (n3 * g * g * g * g);
+}
+
+// lattice_simulate (SU(N)/suncl/suncl.cpp:5212-5505): sample 0 on the initial configuration,
+// NAV thermalisation sweeps, then ITER-1 times { NITER sweeps ; measure }
+void model::lattice_simulate(void)
+{
+    if (SubLat.empty() || !SubLat[0].ctx) throw model_error("lattice_simulate before lattice_init");
+    if (ITER < 1) throw model_error("ITER < 1");
+    for (int i = 0; i < 3; i++) {
+        plq_[i].assign(ITER, 0.0);
+        act_[i].assign(ITER, 0.0);
+    }
+    for (int i = 0; i < 4; i++) pl_[i].assign(ITER, 0.0);
+
+    free(timestart);
+    timestart = current_datetime(&ltimestart);
+    for (auto& s : SubLat) check(qcd_init_lattice(s.ctx), "qcd_init_lattice");
+    int ITER_counter = 0;
+    measure(ITER_counter++);
+    for (int i = 0; i < NAV; i++) {
+        sweep();
+        if (i % 10 == 0) printf("\rGPU thermalization [%i]", i);
+    }
+    for (int i = 1; i < ITER; i++) {
+        for (int j = 0; j < NITER; j++) sweep();
+        if (!turnoff_gramschmidt && lattice_group == 2) {
+            // SU(2) links are products of unit quaternions and are not re-normalised by the
+            // sequential path (SU(N)/suncpp/su2/update_su2.cpp:121); nothing to do
+        }
+        if (i % 10 == 0) printf("\rGPU working iteration [%u]", i);
+        measure(ITER_counter++);
+    }
+    for (auto& s : SubLat) check(qcd_synchronize(s.ctx), "qcd_synchronize");
+    free(timeend);
+    timeend = current_datetime(&ltimeend);
+    printf("\rGPU simulations are done\n");
+}
+
+void model::lattice_analysis(void)
+{
+    Analysis[DM_Plq_spat].data = plq_[0];
+    Analysis[DM_Plq_temp].data = plq_[1];
+    Analysis[DM_Plq_total].data = plq_[2];
+    Analysis[DM_S_spat].data = act_[0];
+    Analysis[DM_S_temp].data = act_[1];
+    Analysis[DM_S_total].data = act_[2];
+    Analysis[DM_Polyakov_loop].data = pl_[0];
+    Analysis[DM_Polyakov_loop_im].data = pl_[1];
+    Analysis[DM_Polyakov_loop_P2].data = pl_[2];
+    Analysis[DM_Polyakov_loop_P4].data = pl_[3];
+    for (int i = 1; i <= DM_max; i++) lattice_data_analysis(&Analysis[i]);
+}
+
+const char* model::lattice_make_header2(void)
+{
+    // SU(N)/suncl/suncl.cpp:797-865, restricted to the observables of this engine
+    char buf[8192];
+    int j = 0;
+    const int n = (int)sizeof(buf);
+    const double dif = difftime(ltimeend, ltimestart);
+    const int elapsdays = (int)(dif / 24 / 3600);
+    const int elapshours = (((int)dif / 3600) % 3600);
+    const int elapsminites = (((int)dif / 60) % 60);
+    const int elapsseconds = (((int)dif) % 60);
+    j += snprintf(buf + j, n - j, " Start time               : %s", timestart ? timestart : "\n");
+    j += snprintf(buf + j, n - j, " Finish time              : %s", timeend ? timeend : "\n");
+    j += snprintf(buf + j, n - j, " Elapsed time             : %i:%2.2i:%2.2i:%2.2i\n", elapsdays, elapshours, elapsminites, elapsseconds);
+    j += snprintf(buf + j, n - j, " ***************************************************\n");
+    static const int order[] = {DM_S_total, DM_Plq_total, DM_Polyakov_loop, DM_Polyakov_loop_im,
+                                DM_Polyakov_loop_P2, DM_Polyakov_loop_P4};
+    for (int idx : order) {
+        j += snprintf(buf + j, n - j, " Mean %-20s: % 16.13e\n", Analysis[idx].data_name, Analysis[idx].mean_value);
+        j += snprintf(buf + j, n - j, " Variance %-16s: % 16.13e\n", Analysis[idx].data_name, Analysis[idx].variance);
+    }
+    j += snprintf(buf + j, n - j, " ***************************************************\n");
+    for (int idx : order)
+        j += snprintf(buf + j, n - j, " GPU last %-16s: % 16.13e\n", Analysis[idx].data_name, Analysis[idx].GPU_last_value);
+    header += buf;
+    return header.c_str();
+}
+
+// result file (SU(N)/suncl/suncl.cpp:1679-1854): <path><prefix>YY-Mon-DD-HH-MM-SS.txt
+void model::lattice_write_results(void)
+{
+    const char* header2 = lattice_make_header2();
+    printf("%s\n", header2);
+    char name[64] = "";
+    if (timeend && strlen(timeend) >= 24)
+        snprintf(name, sizeof(name), "%.2s-%.3s-%.2s-%.2s-%.2s-%.2s.txt", timeend + 22, timeend + 4, timeend + 8,
+                 timeend + 11, timeend + 14, timeend + 17);
+    result_file = path + fprefix + name;
+    FILE* stream = fopen(result_file.c_str(), "w+");
+    if (!stream) throw model_error("cannot write " + result_file);
+    fputs(header.c_str(), stream);
+    fprintf(stream, " ***************************************************\n");
+    fprintf(stream, " Data fields:\n");
+    fprintf(stream, "    #,  ");
+    std::vector<int> cols;
+    if (get_plaquettes_avr) { cols.push_back(DM_Plq_spat); cols.push_back(DM_Plq_temp); cols.push_back(DM_Plq_total); }
+    if (get_actions_avr) { cols.push_back(DM_S_spat); cols.push_back(DM_S_temp); cols.push_back(DM_S_total); }
+    if (PL_level > 0) { cols.push_back(DM_Polyakov_loop); cols.push_back(DM_Polyakov_loop_im); }
+    if (PL_level > 1) { cols.push_back(DM_Polyakov_loop_P2); cols.push_back(DM_Polyakov_loop_P4); }
+    for (int c : cols) fprintf(stream, "%-21s ", Analysis[c].data_name);
+    fprintf(stream, "\n");
+    fprintf(stream, " ***************************************************\n");
+    for (int i = 0; i < ITER; i++) {
+        fprintf(stream, "%5i", i);
+        for (int c : cols) fprintf(stream, " % 16.13e", Analysis[c].data[i]);
+        fprintf(stream, "\n");
+    }
+    if (fclose(stream)) printf("The file was not closed!\n");
+}
+
+// SU(N)/suncl/suncl.cpp:867-905: first five and the last sample
+void model::lattice_print_measurements(void)
+{
+    printf("\n #        ");
+    if (get_plaquettes_avr) printf(" %-11s %-11s", Analysis[DM_Plq_spat].data_name, Analysis[DM_Plq_temp].data_name);
+    if (get_actions_avr) printf(" %-11s %-11s", Analysis[DM_S_spat].data_name, Analysis[DM_S_temp].data_name);
+    if (PL_level > 0) printf(" %-11s %-11s", Analysis[DM_Polyakov_loop].data_name, Analysis[DM_Polyakov_loop_im].data_name);
+    printf("\n");
+    for (int i = 0; i < ITER; i++) {
+        if ((i < 5) || (i == (ITER - 1))) {
+            printf("[%5u]: ", i);
+            if (get_plaquettes_avr) printf(" % 10.8f % 10.8f", Analysis[DM_Plq_spat].data[i], Analysis[DM_Plq_temp].data[i]);
+            if (get_actions_avr) printf(" % 10.8f % 10.8f", Analysis[DM_S_spat].data[i], Analysis[DM_S_temp].data[i]);
+            if (PL_level > 0) printf(" % 10.8f % 10.8f", Analysis[DM_Polyakov_loop].data[i], Analysis[DM_Polyakov_loop_im].data[i]);
+            printf("\n");
+        }
+    }
+}
+
+// per-kernel-class timing report (GPU::print_time_detailed, SU(N)/clinterface/clinterface.cpp:1626-1667)
+void model::print_time_detailed(void)
+{
+    if (!profiling) return;
+    printf("\n kernel class      launches        total ms      avg us\n");
+    for (size_t k = 0; k < SubLat.size(); k++) {
+        qcd_timing t;
+        if (qcd_get_timing(SubLat[k].ctx, &t) != QCD_OK) continue;
+        printf(" part %zu update   %10llu  %14.3f  %10.2f\n", k + 1, t.update_launches, t.update_ms,
+               t.update_launches ? 1e3 * t.update_ms / t.update_launches : 0.0);
+        printf(" part %zu measure  %10llu  %14.3f  %10.2f\n", k + 1, t.measure_launches, t.measure_ms,
+               t.measure_launches ? 1e3 * t.measure_ms / t.measure_launches : 0.0);
+        printf(" part %zu edges    %10llu  %14.3f  %10.2f\n", k + 1, t.halo_launches, t.halo_ms,
+               t.halo_launches ? 1e3 * t.halo_ms / t.halo_launches : 0.0);
+    }
+}
+
+}  // namespace model_HIP

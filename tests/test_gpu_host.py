@@ -1,0 +1,108 @@
+"""The C++ host shell (qcdgpu binary: init.dat -> run -> result file) and BigLattice on a GPU."""
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QCDGPU = os.path.join(ROOT, "qcdgpu_amd", "bin", "qcdgpu")
+
+
+def _run(tmp_path, keys, extra=""):
+    tmp_path.mkdir(exist_ok=True)
+    with open(tmp_path / "init.dat", "w") as f:
+        for k, v in keys.items():
+            f.write("\t%s = %s\n" % (k, v))
+        f.write(extra)
+        f.write("\tOUTPUTPATH = %s/\n" % tmp_path)
+    r = subprocess.run([QCDGPU, str(tmp_path / "init.dat")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    m = re.search(r"result file: (\S+)", r.stdout)
+    rows, fields, in_table = [], None, False
+    text = open(m.group(1)).read()
+    for line in text.splitlines():
+        if line.startswith(" Data fields"):
+            in_table = True
+            continue
+        if in_table and line.strip().startswith("#,"):
+            fields = line.replace("#,", "").split()
+        parts = line.split()
+        if in_table and parts and parts[0].isdigit():
+            rows.append([float(x) for x in parts[1:]])
+    return text, fields, np.array(rows), r.stdout
+
+
+@pytest.mark.parametrize("case", ["ref_su3_8x8x8x8_gid.json", "ref_su2_6x8x4x10_gid.json"])
+def test_cli_reproduces_reference_result_table(tmp_path, case):
+    fx = ol.golden(case)
+    text, fields, rows, _ = _run(tmp_path, fx["init"])
+    assert fields[:6] == ["Plq_spat", "Plq_temp", "Plq_total", "S_spat", "S_temp", "S_total"]
+    want = np.array(fx["samples"], dtype=float)
+    assert rows.shape[0] == fx["init"]["ITER"]
+    assert np.max(np.abs(rows[:, :6] - want) / np.maximum(np.abs(want), 1e-300)) < 1e-12
+    # header lines a parser of the reference's files keys on
+    for label in (" lattice size                :", " ints (0=hot, 1=cold, 2=gid) : 2", " BETA                        :",
+                  " Mean Plq_total", " Variance Plq_total", " Data fields:"):
+        assert label in text
+    mean = float(re.search(r"Mean Plq_total\s*:\s*(\S+)", text).group(1))
+    assert abs(mean - fx["summary"]["Mean Plq_total"]) < 1e-12 * abs(mean)
+
+
+def test_cli_biglattice_equals_single_lattice(tmp_path):
+    """N1 = {..}: the lattice cut into x-slabs (two and three parts on one device, the way the
+    reference exercises BigLattice on one GPU) gives the same run as the uncut lattice."""
+    keys = dict(GROUP=3, ND=4, L1=12, L2=6, L3=6, L4=4, BETA=6.0, NHIT=10, INTS=1, PRNG="RANLUX3",
+                RANDSERIES=54, NAV=1, ITER=3, NITER=1)
+    _, _, single, _ = _run(tmp_path / "a", keys)
+    _, _, two, _ = _run(tmp_path / "b", keys, "\tN1 = {8, 4}\n\tDEVICE = {0, 0}\n")
+    _, _, three, _ = _run(tmp_path / "c", keys, "\tN1 = {2, 6, 4}\n\tDEVICE = {0, 0, 0}\n")
+    # same RANLUX streams (keyed by global site), same arithmetic: identical up to the order of
+    # the final sums of the measurement
+    assert np.max(np.abs(two - single)) < 1e-13
+    assert np.max(np.abs(three - single)) < 1e-13
+    lat = ol.Lattice(3, (12, 6, 6, 4), 6.0, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE)
+    lat.sweep(2)
+    want = np.concatenate([lat.plaquette(), lat.action()])
+    assert np.max(np.abs(single[1, :6] - want) / np.abs(want)) < 1e-11
+    lat.close()
+
+
+def test_biglattice_python_driver_on_one_gpu():
+    """Several slabs on one device through the pack/unpack halves of UpdateEdges."""
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    L = (8, 4, 6, 4)
+    for group, beta in ((3, 5.7), (2, 2.3)):
+        lat = ol.Lattice(group, L, beta, nhit=5, ints=1, rng_mode=ol.RNG_PERSITE, seed=7)
+        big = bl.make_gpu_slabs(group, L, beta, [2, 4, 2], nhit=5, rand_series=7)
+        for s in range(2):
+            big.sweep(1)
+            lat.sweep(1)
+            assert np.max(np.abs(big.plaquette() - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-12
+        assert np.allclose(big.polyakov(), lat.polyakov(), rtol=1e-10, atol=1e-13)
+        draws = sum(e.ctx.rng_draws() for e in big.engines)
+        assert draws == ol.rng_draws(lat)
+        lat.close()
+
+
+def test_gid_biglattice_matches_reference_vector():
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    fx = ol.golden("ref_su3_4x6x8x10_gid.json")
+    a = ol.init_to_args(fx["init"])
+    big = bl.make_gpu_slabs(a["group"], a["L"], a["beta"], [2, 2], nhit=a["nhit"], start_mode=q.START_GID,
+                            rand_series=a["seed"])
+    rows = [np.concatenate([big.plaquette(), big.action()])]
+    big.sweep(a["nav"])
+    for _ in range(1, a["iter_"]):
+        big.sweep(a["niter"])
+        rows.append(np.concatenate([big.plaquette(), big.action()]))
+    want = np.array(fx["samples"], dtype=float)
+    assert np.max(np.abs(np.array(rows) - want) / np.abs(want)) < 1e-12
