@@ -599,6 +599,35 @@ void qo_update_pass(qo_lattice *lat, int parity, int dir)
     }
 }
 
+/* the same pass restricted to the sites with x in [x_begin, x_end): what one slab of a lattice
+ * cut along x does (stream i stays tied to the GLOBAL half-site index i) */
+void qo_update_pass_range(qo_lattice *lat, int parity, int dir, int x_begin, int x_end)
+{
+    const int nd = lat->nd;
+    const int gid_start = (lat->ints == 2);
+    const double beta_eff = lat->beta / lat->group;
+    const int slice = lat->L[1] * lat->L[2] * lat->L[3];
+    for (int i = x_begin * slice / 2; i < x_end * slice / 2; i++) {
+        int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
+        qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[i] : &lat->seq;
+        if (lat->group == 3) {
+            qo_su3 *tab = (qo_su3 *)lat->links;
+            qo_su3 stap, U;
+            qo_staple3(lat, gid, dir, &stap);
+            U = tab[gid * nd + dir];
+            qo_update_link3(&U, &stap, beta_eff, lat->nhit, gid, gid_start, lat->sites, rng, &lat->rng_draws);
+            tab[gid * nd + dir] = U;
+        } else {
+            qo_su2 *tab = (qo_su2 *)lat->links;
+            qo_su2 stap, U;
+            qo_staple2(lat, gid, dir, &stap);
+            U = tab[gid * nd + dir];
+            qo_update_link2(&U, &stap, beta_eff, lat->nhit, gid, gid_start, lat->sites, 1, rng, &lat->rng_draws);
+            tab[gid * nd + dir] = U;
+        }
+    }
+}
+
 void qo_sweep(qo_lattice *lat)
 {
     /* SU(N)/suncpp/suncpp.h:133-141 */
@@ -609,11 +638,25 @@ void qo_sweep(qo_lattice *lat)
 /* ------------------------------------------------------------------------- */
 /* measurements: SU(N)/suncpp/Measurements/Plq.h:46-94, S.h:46-99               */
 
+static void plaquette_sums_range(const qo_lattice *lat, int gid_begin, int gid_end, double *spat, double *temp);
+
 static void plaquette_sums(const qo_lattice *lat, double *spat, double *temp)
+{
+    plaquette_sums_range(lat, 0, lat->sites, spat, temp);
+}
+
+/* raw (spat, temp) sums over the sites with x in [x_begin, x_end) */
+void qo_plaquette_sums_range(const qo_lattice *lat, int x_begin, int x_end, double out[2])
+{
+    const int slice = lat->L[1] * lat->L[2] * lat->L[3];
+    plaquette_sums_range(lat, x_begin * slice, x_end * slice, &out[0], &out[1]);
+}
+
+static void plaquette_sums_range(const qo_lattice *lat, int gid_begin, int gid_end, double *spat, double *temp)
 {
     const int nd = lat->nd;
     double re = 0.0, im = 0.0;
-    for (int gid = 0; gid < lat->sites; gid++) {
+    for (int gid = gid_begin; gid < gid_end; gid++) {
         for (int dir = 0; dir < nd - 2; dir++)
             for (int dir1 = dir + 1; dir1 < nd - 1; dir1++) {
                 int g1 = qo_neighbour(lat->L, gid, dir);
@@ -680,7 +723,28 @@ void qo_action(const qo_lattice *lat, double out[3])
     out[2] = tot;
 }
 
+static void polyakov_sums_range(const qo_lattice *lat, int x_begin, int x_end, double s[4]);
+
+/* raw sums (Re P, Im P, |P|^2, |P|^4) over the spatial sites with x in [x_begin, x_end) */
+void qo_polyakov_sums_range(const qo_lattice *lat, int x_begin, int x_end, double out[4])
+{
+    polyakov_sums_range(lat, x_begin, x_end, out);
+}
+
 void qo_polyakov(const qo_lattice *lat, double out[4])
+{
+    const int *L = lat->L;
+    const int g = lat->group;
+    double s[4];
+    polyakov_sums_range(lat, 0, L[0], s);
+    double n123 = (double)L[0] * L[1] * L[2];
+    out[0] = s[0] / (n123 * g);
+    out[1] = s[1] / (n123 * g);
+    out[2] = s[2] / (n123 * g * g);
+    out[3] = s[3] / (n123 * g * g * g * g);
+}
+
+static void polyakov_sums_range(const qo_lattice *lat, int x_begin, int x_end, double out[4])
 {
     /* SU(N)/suncl/su3cpu.cpp:1383-1433 (su2cpu.cpp twin): ordered product of the T links
      * starting at t = 0; normalisation as :1427-1430.  Parity unpinned (see header). */
@@ -688,7 +752,7 @@ void qo_polyakov(const qo_lattice *lat, double out[4])
     const int *L = lat->L;
     const int g = lat->group;
     double pl = 0.0, pl_im = 0.0, p2 = 0.0, p4 = 0.0;
-    for (int x1 = 0; x1 < L[0]; x1++)
+    for (int x1 = x_begin; x1 < x_end; x1++)
         for (int x2 = 0; x2 < L[1]; x2++)
             for (int x3 = 0; x3 < L[2]; x3++) {
                 int c[4] = { x1, x2, x3, 0 };
@@ -722,11 +786,10 @@ void qo_polyakov(const qo_lattice *lat, double out[4])
                 p2 += q2;
                 p4 += q2 * q2;
             }
-    double n123 = (double)L[0] * L[1] * L[2];
-    out[0] = pl / (n123 * g);
-    out[1] = pl_im / (n123 * g);
-    out[2] = p2 / (n123 * g * g);
-    out[3] = p4 / (n123 * g * g * g * g);
+    out[0] = pl;
+    out[1] = pl_im;
+    out[2] = p2;
+    out[3] = p4;
 }
 
 void qo_estimates(const double *data, int n, double *mean_out, double *var_out)

@@ -94,6 +94,10 @@ void qo_staple3(const qo_lattice *lat, int gid, int dir, qo_su3 *out);
 void qo_staple2(const qo_lattice *lat, int gid, int dir, qo_su2 *out);
 void qo_update_pass(qo_lattice *lat, int parity /*0 even, 1 odd*/, int dir);
 void qo_sweep(qo_lattice *lat);   /* odd X,Y,Z,T then even X,Y,Z,T */
+/* slab variants (x in [x_begin, x_end)) for the multi-rank tests */
+void qo_update_pass_range(qo_lattice *lat, int parity, int dir, int x_begin, int x_end);
+void qo_plaquette_sums_range(const qo_lattice *lat, int x_begin, int x_end, double out[2]);
+void qo_polyakov_sums_range(const qo_lattice *lat, int x_begin, int x_end, double out[4]);
 
 /* one link update with an explicit random source (unit tests) */
 void qo_update_link3(qo_su3 *U, const qo_su3 *stap, double beta_eff, int nhit, int gid,

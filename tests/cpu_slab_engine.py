@@ -1,0 +1,66 @@
+"""A slab engine on top of the CPU checker, with the interface qcdgpu_amd.biglattice expects.
+
+Each rank keeps a full-size link array but owns only the x-slices [x0, x0 + nx); everything
+outside the owned slices and the two halo slices is poisoned with NaN, so a message that is
+missing, late or sent to the wrong side shows up as NaN in the plaquette.  Test infrastructure.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from tests import oracle_lib as ol
+
+ol.lib.qo_update_pass_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+ol.lib.qo_plaquette_sums_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+ol.lib.qo_polyakov_sums_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+
+
+class CpuSlabEngine:
+    def __init__(self, group, L, beta, x0, nx, nhit=10, lux=3, seed=54, ints=1):
+        mode = ol.RNG_GID if ints == 2 else ol.RNG_PERSITE
+        self.lat = ol.Lattice(group, L, beta, nhit=nhit, ints=ints, rng_mode=mode, lux=lux, seed=seed)
+        self.L, self.x0, self.nx = tuple(L), x0, nx
+        self.slice = L[1] * L[2] * L[3]
+        reals = 18 if group == 3 else 8
+        head = C.cast(self.lat.h, C.POINTER(ol._LatticeHead)).contents
+        buf = (C.c_double * (self.lat.sites * 4 * reals)).from_address(head.links)
+        # [x][site in slice][dir][reals]
+        self.links = np.frombuffer(buf, dtype=np.float64).reshape(L[0], self.slice, 4, reals)
+        owned = np.zeros(L[0], dtype=bool)
+        for x in range(x0 - 1, x0 + nx + 1):
+            owned[x % L[0]] = True
+        self.links[~owned] = np.nan
+        c = np.arange(self.slice)
+        y, z, t = c % L[1], (c // L[1]) % L[2], c // (L[1] * L[2])
+        self.yzt_parity = (y + z + t) & 1
+
+    def update(self, parity, direction):
+        ol.lib.qo_update_pass_range(self.lat.h, parity, direction, self.x0, self.x0 + self.nx)
+
+    def _sel(self, x, parity):
+        return ((self.yzt_parity + x) & 1) == parity
+
+    def halo_pack(self, side, direction, parity):
+        x = self.x0 if side == 0 else self.x0 + self.nx - 1
+        return torch.from_numpy(self.links[x, self._sel(x, parity), direction].copy())
+
+    def halo_buffer_like(self, out):
+        return torch.empty_like(out)
+
+    def halo_unpack(self, side, direction, parity, buf):
+        x = (self.x0 - 1) % self.L[0] if side == 0 else (self.x0 + self.nx) % self.L[0]
+        self.links[x, self._sel(x, parity), direction] = buf.numpy()
+
+    def plaquette_sums(self):
+        out = (C.c_double * 2)()
+        ol.lib.qo_plaquette_sums_range(self.lat.h, self.x0, self.x0 + self.nx, out)
+        return np.array(out[:])
+
+    def polyakov_sums(self):
+        out = (C.c_double * 4)()
+        ol.lib.qo_polyakov_sums_range(self.lat.h, self.x0, self.x0 + self.nx, out)
+        return np.array(out[:])
+
+    def reduce_device(self):
+        return "cpu"
