@@ -113,12 +113,20 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("no GPU visible")
+    # rehearsal switches for a one-GPU box (never set by the driver): all ranks on device 0,
+    # halos over gloo through host memory instead of RCCL
+    if os.environ.get("QCDGPU_BENCH_SHARE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("QCDGPU_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     n = args.L
     L = (n * world, n, n, n)
@@ -162,7 +170,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         ev_ms = e0.elapsed_time(e1)
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches = ctx.timing().update_launches - launches0

@@ -70,6 +70,9 @@ class TorchDistComm:
         self.engine = engine
         self.rank, self.world = rank, world
         self.group = group
+        # gloo moves host memory only: device messages are staged through the host (rehearsals
+        # of the GPU path without RCCL; the production backend is "nccl")
+        self.stage_host = dist.get_backend(group) == "gloo"
 
     def exchange(self, direction: int, parity: int):
         dist = self.dist
@@ -79,17 +82,23 @@ class TorchDistComm:
             peer_from = (self.rank - off) % self.world
             out = self.engine.halo_pack(pack_side, direction, parity)
             inp = self.engine.halo_buffer_like(out)
-            ops.append(dist.P2POp(dist.isend, out, peer_to, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, inp, peer_from, group=self.group))
-            recvs.append((recv_side, inp))
+            wire_out, wire_in = out, inp
+            if self.stage_host and out.is_cuda:
+                wire_out, wire_in = out.cpu(), inp.cpu()
+            ops.append(dist.P2POp(dist.isend, wire_out, peer_to, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, wire_in, peer_from, group=self.group))
+            recvs.append((recv_side, inp, wire_in))
         for work in dist.batch_isend_irecv(ops):
             work.wait()
-        for recv_side, inp in recvs:
+        for recv_side, inp, wire_in in recvs:
+            if wire_in is not inp:
+                inp.copy_(wire_in)
             self.engine.halo_unpack(recv_side, direction, parity, inp)
 
     def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
         import torch
-        t = torch.tensor(np.asarray(values, dtype=np.float64), device=self.engine.reduce_device())
+        dev = "cpu" if self.stage_host else self.engine.reduce_device()
+        t = torch.tensor(np.asarray(values, dtype=np.float64), device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
