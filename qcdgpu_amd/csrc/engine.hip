@@ -358,6 +358,13 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
             if (cut < best) { best = cut; g.nzr = cd[0]; g.ntr = cd[1]; }
         }
     }
+    if (const char* ov = getenv("QCDGPU_AMD_REGIONS")) {  // diagnostic override "nzr,ntr"
+        int a = 0, b = 0;
+        if (sscanf(ov, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && g.nz % a == 0 && g.nt % b == 0) {
+            g.nzr = a;
+            g.ntr = b;
+        }
+    }
     g.rz = g.nz / g.nzr;
     g.rt = g.nt / g.ntr;
     g.region_h = g.nyh * g.rz * g.rt;

@@ -395,21 +395,28 @@ __device__ __forceinline__ void update_link(su2& U, const su2& A, double beta, i
 // ---------------------------------------------------------------------------------------------
 // staple sum (SU(N)/suncpp/Update/sun_update.h:43-77): nu ascending, forward then backward
 
+// hb = 16 * half index of x, par = parity of x (wave-uniform)
 template <int GROUP, int DIR>
-__device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, const Geom& g, const Site& x)
+__device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, const Geom& g, const int hb,
+                                             const NbrOff& n, const int par)
 {
     using M = mat<GROUP>;
     M stap = zero<GROUP>();
-    const Site xmu = fwd(g, x, DIR);
+    const int fmu = off_fwd(n, DIR);
     // not unrolled on purpose: one nu at a time keeps six links (not eighteen) in flight per
     // lane, which is what lets two waves per SIMD fit in the register file
 #pragma unroll 1
     for (int k = 0; k < 3; k++) {
         const int nu = (k < DIR) ? k : k + 1;
+        const int fnu = off_fwd(n, nu), bnu = off_bwd(n, nu);
+        const __amdgpu_buffer_rsrc_t r_nu_o = link_rsrc<GROUP>(U, g, nu, par ^ 1);   // U_nu, other parity
+        const __amdgpu_buffer_rsrc_t r_nu_s = link_rsrc<GROUP>(U, g, nu, par);       // U_nu, same parity
+        const __amdgpu_buffer_rsrc_t r_mu_o = link_rsrc<GROUP>(U, g, DIR, par ^ 1);  // U_mu, other parity
         {
-            const M m1 = load_site_link<GROUP>(U, g, nu, xmu);
-            const M m2 = herm(load_site_link<GROUP>(U, g, DIR, fwd(g, x, nu)));
-            const M m3 = herm(load_site_link<GROUP>(U, g, nu, x));
+            // U_nu(x+mu) U_mu(x+nu)^+ U_nu(x)^+
+            const M m1 = load_link_buf(r_nu_o, g, hb + fmu, (M*)nullptr);
+            const M m2 = herm(load_link_buf(r_mu_o, g, hb + fnu, (M*)nullptr));
+            const M m3 = herm(load_link_buf(r_nu_s, g, hb, (M*)nullptr));
 #ifdef QCD_ABL_STAPLE  // diagnostic build: loads kept, products dropped
             add_to(stap, m1); add_to(stap, m2); add_to(stap, m3);
 #else
@@ -417,10 +424,10 @@ __device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, cons
 #endif
         }
         {
-            const Site xb = bwd(g, x, nu);
-            const M m3 = load_site_link<GROUP>(U, g, nu, xb);
-            const M m2 = herm(load_site_link<GROUP>(U, g, DIR, xb));
-            const M m1 = herm(load_site_link<GROUP>(U, g, nu, fwd(g, xb, DIR)));
+            // U_nu(x-nu+mu)^+ U_mu(x-nu)^+ U_nu(x-nu)
+            const M m3 = load_link_buf(r_nu_o, g, hb + bnu, (M*)nullptr);
+            const M m2 = herm(load_link_buf(r_mu_o, g, hb + bnu, (M*)nullptr));
+            const M m1 = herm(load_link_buf(r_nu_s, g, hb + bnu + fmu, (M*)nullptr));
 #ifdef QCD_ABL_STAPLE
             add_to(stap, m1); add_to(stap, m2); add_to(stap, m3);
 #else
@@ -453,9 +460,13 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
     Site x;
     int t;  // stream number = the site pair's half index in the slab
     if (site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) {
-        const int h = half_index(g, x);
-        mat<GROUP> A = staple<GROUP, DIR>(U, g, x);
-        mat<GROUP> Ul = load_link(U, g, DIR, parity, h, (mat<GROUP>*)nullptr);
+        const int hb = half_index(g, x) * 16;
+        const NbrOff nbr = neighbour_offsets(g, x);
+        const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(U, g, DIR, parity);
+        RlxFast<BLOCK, RLX_WINDOW, NSKIP> rs;
+        mat<GROUP> A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
+        mat<GROUP> Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
+        if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
         if (GID) {
             // table index: site number inside the slab
             const size_t lg = (size_t)(((x.xs * g.nt + x.t) * g.nz + x.z)) * g.ny + x.y;
@@ -467,13 +478,11 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
             src.accept[1] = gidr[5 * n + lg];
             update_link<true>(Ul, A, beta_eff, nhit, src);
         } else {
-            RlxFast<BLOCK, RLX_WINDOW, NSKIP> rs;
-            rs.open(rv, t, rbuf + threadIdx.x);
             update_link<false>(Ul, A, beta_eff, nhit, rs);
             int n = rs.close();
             if (n < 0) {
                 // window ran dry: repeat this link from its old value with the general stream
-                Ul = load_link(U, g, DIR, parity, h, (mat<GROUP>*)nullptr);
+                Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
                 RlxStream<BLOCK> slow;
                 slow.open(rv, t, rbuf + threadIdx.x);
                 update_link<false>(Ul, A, beta_eff, nhit, slow);
@@ -481,7 +490,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
             }
             used = (unsigned long long)n;
         }
-        store_link(U, g, DIR, parity, h, Ul);
+        store_link_buf(r_own, g, hb, Ul);
     }
     if (!GID) {
         used = block_sum_u64<BLOCK>(used);

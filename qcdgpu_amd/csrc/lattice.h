@@ -177,4 +177,88 @@ __device__ __forceinline__ void store_link(double2* __restrict__ U, const Geom& 
     for (int c = 0; c < 2; c++) p[(size_t)c * g.vh_alloc] = make_double2(m.e[0][c].re, m.e[0][c].im);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Buffer-descriptor access for the update pass.  One descriptor per (direction, parity)
+// sub-array (wave-uniform, built by scalar instructions); the lane's half index goes into the
+// 32-bit vector offset and the component stride into the scalar offset, so a link costs one
+// integer add per lane instead of six 64-bit address computations.
+
+using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+
+template <int GROUP>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc(const double2* U, const Geom& g, int dir, int par)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(U + comp_base<GROUP>(g, dir, par)), 0,
+                                             ncomp<GROUP>::value * g.vh_alloc * 16, 0x00020000);
+}
+
+// byte_off = 16 * half index
+__device__ __forceinline__ su3 load_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, su3*)
+{
+    su3 m;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, c * g.vh_alloc * 16, 0));
+        m.e[c / 3][c % 3] = mk(v.x, v.y);
+    }
+    reconstruct(m);
+    return m;
+}
+__device__ __forceinline__ su2 load_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, su2*)
+{
+    su2 m;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, c * g.vh_alloc * 16, 0));
+        m.e[0][c] = mk(v.x, v.y);
+    }
+    reconstruct(m);
+    return m;
+}
+__device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, const su3& m)
+{
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im)),
+                                               r, byte_off, c * g.vh_alloc * 16, 0);
+}
+__device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, const su2& m)
+{
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(m.e[0][c].re, m.e[0][c].im)), r, byte_off,
+                                               c * g.vh_alloc * 16, 0);
+}
+
+// byte offsets from a site's half index to its eight nearest neighbours (periodic wrap
+// included; no wrap in x for a slab, whose halo slices are stored in line)
+struct NbrOff {
+    int f0, f1, f2, f3;  // to x + dir
+    int b0, b1, b2, b3;  // to x - dir
+};
+__device__ __forceinline__ NbrOff neighbour_offsets(const Geom& g, const Site& s)
+{
+    NbrOff n;
+    const int sx = g.slice_h * 16, sz = g.nyh * 16, st = g.nyh * g.nz * 16;
+    n.f0 = (!g.halo && s.xs == g.nx - 1) ? -(g.nx - 1) * sx : sx;
+    n.b0 = (!g.halo && s.xs == 0) ? (g.nx - 1) * sx : -sx;
+    const int yb = s.y & 1;
+    n.f1 = (s.y == g.ny - 1) ? -(g.nyh - 1) * 16 : (yb ? 16 : 0);
+    n.b1 = (s.y == 0) ? (g.nyh - 1) * 16 : (yb ? 0 : -16);
+    n.f2 = (s.z == g.nz - 1) ? -(g.nz - 1) * sz : sz;
+    n.b2 = (s.z == 0) ? (g.nz - 1) * sz : -sz;
+    n.f3 = (s.t == g.nt - 1) ? -(g.nt - 1) * st : st;
+    n.b3 = (s.t == 0) ? (g.nt - 1) * st : -st;
+    return n;
+}
+// dir is wave-uniform: the selects are on a scalar condition
+__device__ __forceinline__ int off_fwd(const NbrOff& n, int dir)
+{
+    return dir == 0 ? n.f0 : (dir == 1 ? n.f1 : (dir == 2 ? n.f2 : n.f3));
+}
+__device__ __forceinline__ int off_bwd(const NbrOff& n, int dir)
+{
+    return dir == 0 ? n.b0 : (dir == 1 ? n.b1 : (dir == 2 ? n.b2 : n.b3));
+}
+
 }  // namespace qcd
