@@ -28,9 +28,9 @@ HBM_PEAK_GBS = 8000.0                   # MI355X HBM3E spec peak
 def cpu_baseline(log):
     """Times the CPU path on this host: the reference's own binary (oracle/_ref, one thread, as
     the reference is single-threaded) when it travelled with the tree, else this repo's C port.
-    Bounded sample: SU(3) 16^4, beta 6, NHIT 10, cold start, 8 sweeps (~10 s)."""
+    Bounded sample: SU(3) 16^4, beta 6, NHIT 10, cold start, 32 sweeps (~15 s)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "qcdgpu_cpu")
-    sweeps, L = 8, 16
+    sweeps, L = 32, 16
     sites = L ** 4
     out = None
     if os.path.exists(ref):
@@ -63,7 +63,7 @@ def cpu_baseline(log):
         with open(os.path.join(tmp, "init.dat"), "w") as f:
             f.write("GROUP = 3\nND = 4\nLS = %d\nLT = %d\nBETA = 6.0\nNHIT = 10\nINTS = 1\n"
                     "PRNG = RANLUX3\nRANDSERIES = 54\n" % (L, L))
-        r = subprocess.run([cli, os.path.join(tmp, "init.dat"), "--time-sweeps", str(2 * sweeps)],
+        r = subprocess.run([cli, os.path.join(tmp, "init.dat"), "--time-sweeps", str(sweeps)],
                            check=True, capture_output=True, text=True, timeout=300)
         j = json.loads(r.stdout.strip().splitlines()[-1])
         out = {"value": j["link_updates_per_s"], "unit": "link-updates/s", "cores": 1, "kind": "port",
