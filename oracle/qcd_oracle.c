@@ -119,6 +119,19 @@ float qo_ranlux_next(qo_ranlux *r)
     return uni;
 }
 
+void qo_ranlux_align(qo_ranlux *r)
+{
+    /* Per-thread streams only: drop what is left of the delivered group of 24, so that the next
+     * value is the first of a fresh group.  The reference's device path has the same rule in
+     * another form: every update kernel starts reading at the front of a freshly produced
+     * buffer (SU(N)/suncl/su3_update_cl.cl:679, indprng = GID; PRNG0->produce() in front of
+     * every pass, SU(N)/suncl/suncl.cpp:5357-5377) and the numbers a pass did not use are lost. */
+    while (r->in24 > 0) {
+        (void)rl_step(r);
+        r->in24--;
+    }
+}
+
 int qo_stream_jseed(unsigned randseries, int stream)
 {
     /* stream 0: RL_jseed = rand() % 2147483647 (random.cpp:508); stream i>0 takes the next
@@ -581,6 +594,7 @@ void qo_update_pass(qo_lattice *lat, int parity, int dir)
     for (int i = 0; i < lat->sites / 2; i++) {
         int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
         qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[i] : &lat->seq;
+        if (lat->rng_mode == QO_RNG_PERSITE) qo_ranlux_align(rng);
         if (lat->group == 3) {
             qo_su3 *tab = (qo_su3 *)lat->links;
             qo_su3 stap, U;
@@ -610,6 +624,7 @@ void qo_update_pass_range(qo_lattice *lat, int parity, int dir, int x_begin, int
     for (int i = x_begin * slice / 2; i < x_end * slice / 2; i++) {
         int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
         qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[i] : &lat->seq;
+        if (lat->rng_mode == QO_RNG_PERSITE) qo_ranlux_align(rng);
         if (lat->group == 3) {
             qo_su3 *tab = (qo_su3 *)lat->links;
             qo_su3 stap, U;

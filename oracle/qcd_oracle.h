@@ -63,6 +63,7 @@ int      qo_rand(qo_glibc_rand *g);
 
 void  qo_ranlux_init(qo_ranlux *r, int jseed, int nskip);
 float qo_ranlux_next(qo_ranlux *r);
+void  qo_ranlux_align(qo_ranlux *r);           /* drop the rest of the delivered group of 24 */
 int   qo_nskip_for_level(int level);          /* RANLUX0..4 -> 24,48,97,223,389 */
 int   qo_stream_jseed(unsigned randseries, int stream); /* (stream+1)-th rand() after srand */
 

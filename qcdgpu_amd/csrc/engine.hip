@@ -811,3 +811,11 @@ int qcd_host_gid_randoms(int gid, int nhit, int sites, float out[6])
 }
 
 }  // extern "C"
+
+#ifdef QCD_TRACE
+// diagnostic build only: copies the per-wave phase stamps of the last k_update launch
+extern "C" int qcd_debug_read_trace(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(qcd::g_trace), bytes);
+}
+#endif

@@ -20,40 +20,67 @@
 
 namespace qcd {
 
-// delivered RANLUX batches held in LDS per thread by the update kernel (2 or 3)
-#ifndef QCD_RLX_WINDOW
-#define QCD_RLX_WINDOW 3
-#endif
-constexpr int RLX_WINDOW = QCD_RLX_WINDOW;
+// delivered RANLUX batches held in LDS per thread by the update kernel
+constexpr int RLX_WINDOW = 2;
 
 // ---------------------------------------------------------------------------------------------
 // random sources of the heat-bath
+//
+// Consumption rule of a per-thread stream: every link update starts at the first value of a
+// fresh batch of 24; what the previous update left of its last batch is dropped.  (The
+// reference's device path has the same rule in another form: each update kernel reads from the
+// front of a buffer produced just for it, SU(N)/suncl/su3_update_cl.cl:679 and
+// SU(N)/suncl/suncl.cpp:5357-5377.)  The persistent state of a stream is therefore just the
+// generator state in front of its next batch.
 
 struct RlxView {
-    unsigned* slot0;    // [w * ns + stream], w in [0, 25): state in front of a batch
-    unsigned* slot1;    // second copy: the batch after / before the one in slot0
-    unsigned* ctl;      // bit 0: slot holding the current batch's state; bits 1..: values used
+    unsigned* slot0;    // [w * ns + stream], w in [0, 25): generator state in front of a batch
+    unsigned* slot1;    // second copy; ctl says which of the two is current
+    unsigned* ctl;      // bit 0: slot that holds the state in front of the stream's next batch
     int ns;             // streams
     int q, rem;         // nskip = 24*q + rem
 };
 
-// Common part: where a stream's persistent state lives.
+// Where a stream's persistent state lives, and the moves both stream types share.
 struct RlxHome {
     unsigned* __restrict__ s0;   // this stream's column in slot 0 / slot 1
     unsigned* __restrict__ s1;
     unsigned* __restrict__ ctl;
     int ns, q, rem;
+
+    __device__ __forceinline__ void bind(const RlxView& view, int stream)
+    {
+        s0 = view.slot0 + stream;
+        s1 = view.slot1 + stream;
+        ctl = view.ctl + stream;
+        ns = view.ns;
+        q = view.q;
+        rem = view.rem;
+    }
+    __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
+    {
+        const unsigned* __restrict__ p = slot ? s1 : s0;
+#pragma unroll
+        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * ns];
+        r.c = p[(size_t)24 * ns];
+    }
+    __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
+    {
+        unsigned* __restrict__ p = slot ? s1 : s0;
+#pragma unroll
+        for (int w = 0; w < 24; w++) p[(size_t)w * ns] = r.s[w];
+        p[(size_t)24 * ns] = r.c;
+    }
 };
 
-// The stream as the update kernel normally uses it: NB delivered batches (24*NB values) are
-// written to LDS column `tid` when the stream is opened, and the generator state is dead after
-// that -- no registers held, no branch into generator code while the heat-bath runs.  A link
-// update needs 18 values plus 4 per rejected trial; at least 24*(NB-1) are always on hand.  A
+// The stream as the update kernel normally uses it: two delivered batches (48 values) are
+// written to LDS column `tid` when the stream is opened, and the generator is dead after that --
+// no registers held, no branch into generator code while the heat-bath runs.  An SU(3) link
+// update needs 18 values plus 4 per rejected trial, so the window covers seven rejections.  A
 // thread that runs dry reports it (close() < 0) and the kernel repeats that one link with the
 // general stream below, starting from the same persistent state.
-template <int BLOCK, int NB, int NSKIP>
+template <int BLOCK, int NSKIP>
 struct RlxFast {
-    static_assert(NB == 2 || NB == 3, "window of two or three batches");
     __device__ __forceinline__ void skip(RlxRegs& r) const
     {
         if (NSKIP > 0) rlx_skip_static<(NSKIP > 0 ? NSKIP : 24)>(r);
@@ -61,53 +88,29 @@ struct RlxFast {
     }
     const float* buf;
     RlxHome h;
-    int pos, pos0, cur;
+    int pos, cur;
     bool dry;
 
-    __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
-    {
-        const unsigned* __restrict__ p = slot ? h.s1 : h.s0;
-#pragma unroll
-        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * h.ns];
-        r.c = p[(size_t)24 * h.ns];
-    }
-    __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
-    {
-        unsigned* __restrict__ p = slot ? h.s1 : h.s0;
-#pragma unroll
-        for (int w = 0; w < 24; w++) p[(size_t)w * h.ns] = r.s[w];
-        p[(size_t)24 * h.ns] = r.c;
-    }
     __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
     {
-        h.s0 = view.slot0 + stream;
-        h.s1 = view.slot1 + stream;
-        h.ctl = view.ctl + stream;
-        h.ns = view.ns;
-        h.q = view.q;
-        h.rem = view.rem;
+        h.bind(view, stream);
         buf = lds_column;
         dry = false;
-        const unsigned c = *h.ctl;
-        cur = (int)(c & 1u);
-        pos = pos0 = (int)(c >> 1);
+        pos = 0;
+        cur = (int)(*h.ctl & 1u);
 #ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
         return;
 #endif
         RlxRegs r;
-        load_state(r, cur);
+        h.load_state(r, cur);
         rlx_batch(r, lds_column, BLOCK);
         skip(r);
-        store_state(r, cur ^ 1);
+        h.store_state(r, cur ^ 1);   // in front of the second batch: the usual next state
         rlx_batch(r, lds_column + 24 * BLOCK, BLOCK);
-        if (NB == 3) {
-            skip(r);
-            rlx_batch(r, lds_column + 48 * BLOCK, BLOCK);
-        }
     }
     __device__ __forceinline__ float next()
     {
-        if (pos >= 24 * NB) {
+        if (pos >= 24 * RLX_WINDOW) {
             dry = true;
             return 0.5f;
         }
@@ -128,19 +131,18 @@ struct RlxFast {
     __device__ __forceinline__ int close()
     {
         if (dry) return -1;
-        int m = pos / 24;
-        if (m > NB - 1) m = NB - 1;
-        if (m == 2) {
-            // rare: the state in front of the third batch was not kept; rebuild it from the one
-            // in front of the second
+        if (pos > 24) {
+            // rare (two or more rejected trials): the second batch was touched, the stream
+            // resumes in front of the third; rebuild that state from the one in front of the second
             RlxRegs r;
-            load_state(r, cur ^ 1);
+            h.load_state(r, cur ^ 1);
             rlx_round(r);
             skip(r);
-            store_state(r, cur);
+            h.store_state(r, cur);
+        } else {
+            *h.ctl = (unsigned)(cur ^ 1);
         }
-        *h.ctl = (unsigned)((cur ^ (m & 1)) | ((pos - 24 * m) << 1));
-        return pos - pos0;
+        return pos;
     }
 };
 
@@ -150,58 +152,41 @@ struct RlxFast {
 template <int BLOCK>
 struct RlxStream {
     float* buf;
-    unsigned* __restrict__ s0;   // this stream's column in slot 0 / slot 1
-    unsigned* __restrict__ s1;
-    unsigned* __restrict__ ctl;
-    int ns, q, rem;
-    int pos, pos0, nb, cur;
+    RlxHome h;
+    int pos, nb, cur;   // nb batches delivered so far; state in front of batch k is in slot cur^(k&1)
+                        // for k = nb-1 and k = nb-2
 
-    __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
-    {
-        const unsigned* __restrict__ p = slot ? s1 : s0;
-#pragma unroll
-        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * ns];
-        r.c = p[(size_t)24 * ns];
-    }
-    __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
-    {
-        unsigned* __restrict__ p = slot ? s1 : s0;
-#pragma unroll
-        for (int w = 0; w < 24; w++) p[(size_t)w * ns] = r.s[w];
-        p[(size_t)24 * ns] = r.c;
-    }
     __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
     {
-        s0 = view.slot0 + stream;
-        s1 = view.slot1 + stream;
-        ctl = view.ctl + stream;
-        ns = view.ns;
-        q = view.q;
-        rem = view.rem;
+        h.bind(view, stream);
         buf = lds_column;
-        const unsigned c = *ctl;
-        cur = (int)(c & 1u);
-        pos = pos0 = (int)(c >> 1);
+        pos = 0;
+        cur = (int)(*h.ctl & 1u);
 #ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
         nb = 1000;
         return;
 #endif
         RlxRegs r;
-        load_state(r, cur);
+        h.load_state(r, cur);
         rlx_batch(r, buf, BLOCK);
-        rlx_skip(r, q, rem);
-        store_state(r, cur ^ 1);
+        rlx_skip(r, h.q, h.rem);
+        h.store_state(r, cur ^ 1);
         rlx_batch(r, buf + 24 * BLOCK, BLOCK);
         nb = 2;
     }
-    // both delivered batches are used up: rebuild the state behind the newest one and go on
+    // state in front of batch nb from the one in front of batch nb-1
+    __device__ __forceinline__ void advance(RlxRegs& r)
+    {
+        h.load_state(r, cur ^ ((nb - 1) & 1));
+        rlx_round(r);
+        rlx_skip(r, h.q, h.rem);
+        h.store_state(r, cur ^ (nb & 1));
+    }
+    // both delivered batches are used up: deliver the next one over the older
     __device__ __noinline__ void refill()
     {
         RlxRegs r;
-        load_state(r, cur ^ ((nb - 1) & 1));
-        rlx_round(r);
-        rlx_skip(r, q, rem);
-        store_state(r, cur ^ (nb & 1));
+        advance(r);
         rlx_batch(r, buf + (nb & 1) * 24 * BLOCK, BLOCK);
         nb++;
     }
@@ -226,10 +211,18 @@ struct RlxStream {
     }
     __device__ __forceinline__ int close()
     {
-        int m = pos / 24;
-        if (m > nb - 1) m = nb - 1;
-        *ctl = (unsigned)((cur ^ (m & 1)) | ((pos - 24 * m) << 1));
-        return pos - pos0;
+#ifndef QCD_ABL_RNG
+        // the stream resumes in front of the batch after the last one touched
+        const int m = (pos - 1) / 24;
+        if (m == nb - 1) {
+            RlxRegs r;
+            advance(r);
+            *h.ctl = (unsigned)(cur ^ (nb & 1));
+        } else {
+            *h.ctl = (unsigned)(cur ^ ((m + 1) & 1));
+        }
+#endif
+        return pos;
     }
 };
 
@@ -441,6 +434,19 @@ __device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, cons
 // ---------------------------------------------------------------------------------------------
 // update pass
 
+#ifdef QCD_TRACE  // diagnostic build: per-wave time stamps of the phases of k_update
+__device__ unsigned long long g_trace[8192 * 8];
+#define QCD_STAMP(k)                                                                         \
+    do {                                                                                     \
+        if ((threadIdx.x & 63) == 0) {                                                       \
+            const unsigned w_ = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);              \
+            if (w_ < 8192) g_trace[w_ * 8 + (k)] = __builtin_readcyclecounter();             \
+        }                                                                                    \
+    } while (0)
+#else
+#define QCD_STAMP(k) do {} while (0)
+#endif
+
 template <int BLOCK>
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v)
 {
@@ -449,8 +455,11 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
     return v;  // valid in lane 0 of each wave
 }
 
+#ifndef QCD_UPD_WAVES
+#define QCD_UPD_WAVES 2   // waves per SIMD the register budget is set for
+#endif
 template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, const Geom g, const int parity,
+__global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(double2* __restrict__ U, const Geom g, const int parity,
                                                   const double beta_eff, const int nhit, const RlxView rv,
                                                   const float* __restrict__ gidr,
                                                   unsigned long long* __restrict__ draws)
@@ -459,14 +468,31 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
     unsigned long long used = 0;
     Site x;
     int t;  // stream number = the site pair's half index in the slab
+#ifdef QCD_STAG_PH  // experiment: de-synchronise the first round of workgroups
+    if (blockIdx.x < 1024) {
+        const int j = blockIdx.x >> 3;
+        const int k = (QCD_STAG_SHIFT < 0 ? ((j * 0x9E3779B1u) >> 20) : (j >> QCD_STAG_SHIFT)) % QCD_STAG_PH;
+        for (int i = 0; i < k * QCD_STAG_SLEEPS; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     if (site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) {
         const int hb = half_index(g, x) * 16;
         const NbrOff nbr = neighbour_offsets(g, x);
         const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(U, g, DIR, parity);
-        RlxFast<BLOCK, RLX_WINDOW, NSKIP> rs;
+        RlxFast<BLOCK, NSKIP> rs;
+        QCD_STAMP(0);
+#ifdef QCD_TRACE
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned w_ = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+            if (w_ < 8192) g_trace[w_ * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+            if (w_ < 8192) g_trace[w_ * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+        }
+#endif
         mat<GROUP> A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
+        QCD_STAMP(1);
         mat<GROUP> Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
         if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
+        QCD_STAMP(2);
         if (GID) {
             // table index: site number inside the slab
             const size_t lg = (size_t)(((x.xs * g.nt + x.t) * g.nz + x.z)) * g.ny + x.y;
@@ -479,6 +505,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
             update_link<true>(Ul, A, beta_eff, nhit, src);
         } else {
             update_link<false>(Ul, A, beta_eff, nhit, rs);
+            QCD_STAMP(3);
             int n = rs.close();
             if (n < 0) {
                 // window ran dry: repeat this link from its old value with the general stream
@@ -491,6 +518,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_update(double2* __restrict__ U, co
             used = (unsigned long long)n;
         }
         store_link_buf(r_own, g, hb, Ul);
+        QCD_STAMP(4);
     }
     if (!GID) {
         used = block_sum_u64<BLOCK>(used);
