@@ -44,7 +44,11 @@ int fail(int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-constexpr int UPD_BLOCK = 128;
+#ifndef QCD_UPD_BLOCK
+#define QCD_UPD_BLOCK 128
+#endif
+constexpr int UPD_BLOCK = QCD_UPD_BLOCK;
+constexpr int REDO_BLOCK = 64, REDO_GRID = 512;
 constexpr int MEAS_BLOCK = 256;
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -57,6 +61,7 @@ struct qcd_ctx {
     hipEvent_t edge_ev;
     Geom g;
     int ncomp;
+    int upd_grid;             // workgroups per update launch (0: one per block of sites)
     hipStream_t own_stream, stream;
     double2* U;
     size_t U_elems;
@@ -68,6 +73,9 @@ struct qcd_ctx {
     double* result_host;  // pinned
     unsigned long long* draws_dev;
     unsigned long long* draws_host;  // pinned
+    int* redo_list;           // update pass: sites left to the general random stream
+    unsigned* redo_count;     // two counters, used by alternate passes
+    unsigned pass_no;
     bool initialized;
     bool profiling;
     hipEvent_t ev0, ev1;
@@ -75,6 +83,8 @@ struct qcd_ctx {
 };
 
 namespace {
+
+inline int regions_of(const Geom& g) { return g.nzr * g.ntr; }
 
 int set_device(const qcd_ctx* c)
 {
@@ -113,11 +123,31 @@ template <int GROUP, bool GID, int NSKIP>
 int launch_update_dir(qcd_ctx* c, int parity, int dir)
 {
     const Geom& g = c->g;
-    const dim3 grid(g.nzr * g.ntr * cdiv((long)g.nx * g.region_h, UPD_BLOCK)), block(UPD_BLOCK);
+    const int regions = g.nzr * g.ntr;
+    const int nblocks = regions * (int)cdiv((long)g.nx * g.region_h, UPD_BLOCK);
+    // launch no more workgroups than the device holds at one time and let each walk several
+    // blocks of sites: a finished wave goes straight on to its next site instead of waiting for
+    // its stores to drain and for the dispatcher to start a successor
+    int nwg = nblocks;
+    if (c->upd_grid > 0 && c->upd_grid < nblocks) nwg = c->upd_grid;
+    const dim3 grid(nwg), block(UPD_BLOCK);
     const double beta_eff = c->p.beta / c->p.group;  // SU(N)/suncpp/Update/sun_update.h:94
+    UpdArgs a;
+    a.U = c->U;
+    a.g = g;
+    a.parity = parity;
+    a.nhit = c->p.nhit;
+    a.beta_eff = beta_eff;
+    a.rv = c->rv;
+    a.gidr = c->gidr;
+    a.draws = c->draws_dev;
+    a.nblocks = nblocks;
+    a.redo_list = c->redo_list;
+    a.redo_count = c->redo_count + (c->pass_no & 1u);
+    a.redo_count_next = c->redo_count + ((c->pass_no + 1u) & 1u);
+    c->pass_no++;
 #define QCD_LAUNCH_UPDATE(D) \
-    hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, \
-                       beta_eff, c->p.nhit, c->rv, c->gidr, c->draws_dev)
+    hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, c->stream, a)
     switch (dir) {
         case 0: QCD_LAUNCH_UPDATE(0); break;
         case 1: QCD_LAUNCH_UPDATE(1); break;
@@ -125,6 +155,19 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir)
         default: QCD_LAUNCH_UPDATE(3); break;
     }
 #undef QCD_LAUNCH_UPDATE
+    if (!GID) {
+        // the few sites (none at large beta) whose random window ran dry; also re-arms the list
+        const dim3 rgrid(REDO_GRID), rblock(REDO_BLOCK);
+#define QCD_LAUNCH_REDO(D) \
+    hipLaunchKernelGGL((k_update_redo<GROUP, D, REDO_BLOCK, UPD_BLOCK>), rgrid, rblock, 0, c->stream, a)
+        switch (dir) {
+            case 0: QCD_LAUNCH_REDO(0); break;
+            case 1: QCD_LAUNCH_REDO(1); break;
+            case 2: QCD_LAUNCH_REDO(2); break;
+            default: QCD_LAUNCH_REDO(3); break;
+        }
+#undef QCD_LAUNCH_REDO
+    }
     return QCD_OK;
 }
 
@@ -368,6 +411,34 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     g.rz = g.nz / g.nzr;
     g.rt = g.nt / g.ntr;
     g.region_h = g.nyh * g.rz * g.rt;
+    g.tz = g.tt = g.tx = 0;
+    if (const char* ov = getenv("QCDGPU_AMD_TILE")) {  // diagnostic override "tz,tt,tx"
+        int a = 0, b = 0, d = 0;
+        if (sscanf(ov, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0 && UPD_BLOCK % g.nyh == 0 &&
+            a * b * d == UPD_BLOCK / g.nyh && g.rz % a == 0 && g.rt % b == 0 && g.nx % d == 0) {
+            g.tz = a;
+            g.tt = b;
+            g.tx = d;
+        }
+    }
+    // update launches: as many workgroups as the device holds at one time (a multiple of the
+    // region count, so that a workgroup stays inside one region)
+    c->upd_grid = 0;
+    {
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        const void* fn = (p->group == 3) ? (const void*)k_update<3, 0, false, 223, UPD_BLOCK>
+                                         : (const void*)k_update<2, 0, false, 223, UPD_BLOCK>;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, UPD_BLOCK, 0) == hipSuccess && per_cu > 0) {
+            const int resident = per_cu * prop.multiProcessorCount;
+            c->upd_grid = resident / regions_of(g) * regions_of(g);
+        }
+    }
+    if (const char* ov = getenv("QCDGPU_AMD_GRID")) {  // diagnostic override: workgroups per update launch
+        const int v = atoi(ov);                        // (0: one workgroup per block of sites)
+        c->upd_grid = v > 0 ? (v + regions_of(g) - 1) / regions_of(g) * regions_of(g) : 0;
+    }
     c->ncomp = (p->group == 3) ? 6 : 2;
     c->U_elems = (size_t)8 * c->ncomp * g.vh_alloc;
     c->npartial = cdiv(2L * g.vh_int, MEAS_BLOCK);
@@ -382,8 +453,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
     tryhip(hipMalloc(&c->U, c->U_elems * sizeof(double2)), "hipMalloc(links)");
     const size_t stw = (size_t)RLX_STATE_WORDS * g.vh_int * sizeof(unsigned);
-    tryhip(hipMalloc(&c->rv.slot0, stw), "hipMalloc(ranlux)");
-    tryhip(hipMalloc(&c->rv.slot1, stw), "hipMalloc(ranlux)");
+    tryhip(hipMalloc(&c->rv.slot0, 2 * stw), "hipMalloc(ranlux)");   // both slots, back to back
+    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_STATE_WORDS * g.vh_int : nullptr;
     tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh_int * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
     c->rv.ns = g.vh_int;
     if (p->start_mode == QCD_START_GID)
@@ -392,6 +463,9 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipMalloc(&c->result_dev, 8 * sizeof(double)), "hipMalloc(result)");
     tryhip(hipHostMalloc(&c->result_host, 8 * sizeof(double)), "hipHostMalloc(result)");
     tryhip(hipMalloc(&c->draws_dev, sizeof(unsigned long long)), "hipMalloc(draws)");
+    tryhip(hipMalloc(&c->redo_list, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list)");
+    tryhip(hipMalloc(&c->redo_count, 2 * sizeof(unsigned)), "hipMalloc(redo count)");
+    if (rc == QCD_OK) tryhip(hipMemset(c->redo_count, 0, 2 * sizeof(unsigned)), "hipMemset(redo count)");
     tryhip(hipHostMalloc(&c->draws_host, sizeof(unsigned long long)), "hipHostMalloc(draws)");
     if (rc != QCD_OK) {
         qcd_destroy(c);
@@ -408,7 +482,6 @@ void qcd_destroy(qcd_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->U);
     (void)hipFree(c->rv.slot0);
-    (void)hipFree(c->rv.slot1);
     (void)hipFree(c->rv.ctl);
     (void)hipFree(c->gidr);
     (void)hipFree(c->edge_buf);
@@ -416,6 +489,8 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipFree(c->partial);
     (void)hipFree(c->result_dev);
     (void)hipFree(c->draws_dev);
+    (void)hipFree(c->redo_list);
+    (void)hipFree(c->redo_count);
     if (c->result_host) (void)hipHostFree(c->result_host);
     if (c->draws_host) (void)hipHostFree(c->draws_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -35,7 +35,7 @@ constexpr int RLX_WINDOW = 2;
 
 struct RlxView {
     unsigned* slot0;    // [w * ns + stream], w in [0, 25): generator state in front of a batch
-    unsigned* slot1;    // second copy; ctl says which of the two is current
+    unsigned* slot1;    // second copy = slot0 + 25*ns (one allocation); ctl says which of the two is current
     unsigned* ctl;      // bit 0: slot that holds the state in front of the stream's next batch
     int ns;             // streams
     int q, rem;         // nskip = 24*q + rem
@@ -43,15 +43,13 @@ struct RlxView {
 
 // Where a stream's persistent state lives, and the moves both stream types share.
 struct RlxHome {
-    unsigned* __restrict__ s0;   // this stream's column in slot 0 / slot 1
-    unsigned* __restrict__ s1;
+    unsigned* __restrict__ s0;   // this stream's column in slot 0; slot 1 lies 25*ns words behind it
     unsigned* __restrict__ ctl;
     int ns, q, rem;
 
     __device__ __forceinline__ void bind(const RlxView& view, int stream)
     {
         s0 = view.slot0 + stream;
-        s1 = view.slot1 + stream;
         ctl = view.ctl + stream;
         ns = view.ns;
         q = view.q;
@@ -59,14 +57,14 @@ struct RlxHome {
     }
     __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
     {
-        const unsigned* __restrict__ p = slot ? s1 : s0;
+        const unsigned* __restrict__ p = s0 + (size_t)slot * RLX_STATE_WORDS * ns;
 #pragma unroll
         for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * ns];
         r.c = p[(size_t)24 * ns];
     }
     __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
     {
-        unsigned* __restrict__ p = slot ? s1 : s0;
+        unsigned* __restrict__ p = s0 + (size_t)slot * RLX_STATE_WORDS * ns;
 #pragma unroll
         for (int w = 0; w < 24; w++) p[(size_t)w * ns] = r.s[w];
         p[(size_t)24 * ns] = r.c;
@@ -431,6 +429,192 @@ __device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, cons
     return stap;
 }
 
+// SU(3) staple sum, software-pipelined and with a small register footprint.  Every staple term
+// is itself an SU(3) matrix, so only its first two rows are formed by products (from two rows of
+// the leading factor and the full other factor) and the third row is (row0 x row1)*, the rule the
+// stored links are completed by; rounding differs from full 3x3 products in the last bit only.
+// The loads of a term are requested while the products of the one before are computed, so a
+// wave's memory latency hides behind its own arithmetic and not only behind the other wave of
+// the SIMD.
+struct rows2 {
+    cplx e[2][3];
+};
+__device__ __forceinline__ cplx dot3c(cplx a1, cplx a2, cplx a3, cplx b1, cplx b2, cplx b3)
+{
+    return dot3(a1, a2, a3, conj(b1), conj(b2), conj(b3));
+}
+
+struct raw_link {
+    double2 c[6];
+};
+__device__ __forceinline__ raw_link issue_link(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off)
+{
+    raw_link l;
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+        l.c[c] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, c * g.vh_alloc * 16, 0));
+    return l;
+}
+__device__ __forceinline__ rows2 as_rows2(const raw_link& l)
+{
+    rows2 m;
+#pragma unroll
+    for (int c = 0; c < 6; c++) m.e[c / 3][c % 3] = mk(l.c[c].x, l.c[c].y);
+    return m;
+}
+__device__ __forceinline__ su3 as_su3(const raw_link& l)
+{
+    su3 m;
+#pragma unroll
+    for (int c = 0; c < 6; c++) m.e[c / 3][c % 3] = mk(l.c[c].x, l.c[c].y);
+    reconstruct(m);
+    return m;
+}
+// Ordering pins for the pipeline below.  The instruction selector is free to sink arithmetic
+// below later loads (and then everything is in flight at once and spills); an empty volatile asm
+// that takes the values as in/out operands and clobbers memory fixes the order: loads cannot
+// cross it, and arithmetic on the pinned values cannot start before / finish after it.
+__device__ __forceinline__ void pin(raw_link& l)
+{
+    asm volatile("" : "+v"(l.c[0].x), "+v"(l.c[0].y), "+v"(l.c[1].x), "+v"(l.c[1].y), "+v"(l.c[2].x), "+v"(l.c[2].y),
+                      "+v"(l.c[3].x), "+v"(l.c[3].y), "+v"(l.c[4].x), "+v"(l.c[4].y), "+v"(l.c[5].x), "+v"(l.c[5].y)
+                 :: "memory");
+}
+__device__ __forceinline__ void pin(su3& m)
+{
+    asm volatile("" : "+v"(m.e[0][0].re), "+v"(m.e[0][0].im), "+v"(m.e[0][1].re), "+v"(m.e[0][1].im),
+                      "+v"(m.e[0][2].re), "+v"(m.e[0][2].im), "+v"(m.e[1][0].re), "+v"(m.e[1][0].im),
+                      "+v"(m.e[1][1].re), "+v"(m.e[1][1].im), "+v"(m.e[1][2].re), "+v"(m.e[1][2].im),
+                      "+v"(m.e[2][0].re), "+v"(m.e[2][0].im), "+v"(m.e[2][1].re), "+v"(m.e[2][1].im),
+                      "+v"(m.e[2][2].re), "+v"(m.e[2][2].im)
+                 :: "memory");
+}
+// term 2k: forward staple in the k-th direction nu != DIR, term 2k+1: the backward one.
+// The first two links of term k+1 are requested before the second product of term k, its third
+// link before the first product of term k+1.
+struct raw_pair {
+    raw_link a, b;
+};
+__device__ __forceinline__ void pin(raw_pair& t)
+{
+    pin(t.a);
+    pin(t.b);
+}
+__device__ __forceinline__ void pin(rows2& m)
+{
+    asm volatile("" : "+v"(m.e[0][0].re), "+v"(m.e[0][0].im), "+v"(m.e[0][1].re), "+v"(m.e[0][1].im),
+                      "+v"(m.e[0][2].re), "+v"(m.e[0][2].im), "+v"(m.e[1][0].re), "+v"(m.e[1][0].im),
+                      "+v"(m.e[1][1].re), "+v"(m.e[1][1].im), "+v"(m.e[1][2].re), "+v"(m.e[1][2].im)
+                 :: "memory");
+}
+template <int DIR, int TERM>
+__device__ __forceinline__ raw_pair issue_ab(const double2* __restrict__ U, const Geom& g, const int hb,
+                                             const NbrOff& n, const int par)
+{
+    constexpr int k = TERM / 2;
+    constexpr int nu = (k < DIR) ? k : k + 1;
+    const int fmu = off_fwd(n, DIR);
+    raw_pair t;
+    if (TERM % 2 == 0) {
+        t.a = issue_link(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + fmu);
+        t.b = issue_link(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + off_fwd(n, nu));
+    } else {
+        const int bnu = off_bwd(n, nu);
+        t.a = issue_link(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + bnu);
+        t.b = issue_link(link_rsrc<3>(U, g, nu, par), g, hb + bnu + fmu);
+    }
+    return t;
+}
+template <int DIR, int TERM>
+__device__ __forceinline__ raw_link issue_c(const double2* __restrict__ U, const Geom& g, const int hb,
+                                            const NbrOff& n, const int par)
+{
+    constexpr int k = TERM / 2;
+    constexpr int nu = (k < DIR) ? k : k + 1;
+    if (TERM % 2 == 0) return issue_link(link_rsrc<3>(U, g, nu, par), g, hb);
+    return issue_link(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_bwd(n, nu));
+}
+// first product of a term: two rows of a * b^+ (forward) or of a * b (backward)
+template <int TERM>
+__device__ __forceinline__ rows2 first_product(const raw_pair& t)
+{
+    const rows2 a = as_rows2(t.a);
+    const su3 b = as_su3(t.b);
+    rows2 p;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            p.e[i][j] = (TERM % 2 == 0) ? dot3c(a.e[i][0], a.e[i][1], a.e[i][2], b.e[j][0], b.e[j][1], b.e[j][2])
+                                        : dot3(a.e[i][0], a.e[i][1], a.e[i][2], b.e[0][j], b.e[1][j], b.e[2][j]);
+    return p;
+}
+// second product and accumulation: p * c^+ (forward), p^+ * c (backward, p completed first)
+template <int TERM>
+__device__ __forceinline__ void second_product(su3& stap, const rows2& p2, const raw_link& cl)
+{
+    const su3 c = as_su3(cl);
+    su3 r;
+    if (TERM % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                r.e[i][j] = dot3c(p2.e[i][0], p2.e[i][1], p2.e[i][2], c.e[j][0], c.e[j][1], c.e[j][2]);
+    } else {
+        su3 p;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) p.e[i][j] = p2.e[i][j];
+        reconstruct(p);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                r.e[i][j] = dot3(conj(p.e[0][i]), conj(p.e[1][i]), conj(p.e[2][i]), c.e[0][j], c.e[1][j], c.e[2][j]);
+    }
+    reconstruct(r);
+    add_to(stap, r);
+}
+template <int DIR, int TERM>
+__device__ __forceinline__ void pipe_step(su3& stap, raw_pair& ab, raw_link& c, const double2* __restrict__ U,
+                                           const Geom& g, const int hb, const NbrOff& n, const int par)
+{
+    pin(ab);
+    rows2 p = first_product<TERM>(ab);
+    pin(p);
+    if (TERM < 5) ab = issue_ab<DIR, (TERM < 5 ? TERM + 1 : 5)>(U, g, hb, n, par);
+    pin(c);
+    second_product<TERM>(stap, p, c);
+    pin(stap);
+    if (TERM < 5) c = issue_c<DIR, (TERM < 5 ? TERM + 1 : 5)>(U, g, hb, n, par);
+}
+template <int DIR>
+__device__ __forceinline__ su3 staple_pipe(const double2* __restrict__ U, const Geom& g, const int hb,
+                                            const NbrOff& n, const int par)
+{
+    su3 stap = zero<3>();
+    raw_pair ab = issue_ab<DIR, 0>(U, g, hb, n, par);
+    raw_link c = issue_c<DIR, 0>(U, g, hb, n, par);
+    pipe_step<DIR, 0>(stap, ab, c, U, g, hb, n, par);
+    pipe_step<DIR, 1>(stap, ab, c, U, g, hb, n, par);
+    pipe_step<DIR, 2>(stap, ab, c, U, g, hb, n, par);
+    pipe_step<DIR, 3>(stap, ab, c, U, g, hb, n, par);
+    pipe_step<DIR, 4>(stap, ab, c, U, g, hb, n, par);
+    pipe_step<DIR, 5>(stap, ab, c, U, g, hb, n, par);
+    return stap;
+}
+
+template <int GROUP, int DIR>
+__device__ __forceinline__ mat<GROUP> staple_for_update(const double2* __restrict__ U, const Geom& g, const int hb,
+                                                        const NbrOff& n, const int par)
+{
+    if constexpr (GROUP == 3) return staple_pipe<DIR>(U, g, hb, n, par);
+    else
+    return staple<GROUP, DIR>(U, g, hb, n, par);
+}
+
 // ---------------------------------------------------------------------------------------------
 // update pass
 
@@ -439,8 +623,8 @@ __device__ unsigned long long g_trace[8192 * 8];
 #define QCD_STAMP(k)                                                                         \
     do {                                                                                     \
         if ((threadIdx.x & 63) == 0) {                                                       \
-            const unsigned w_ = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);              \
-            if (w_ < 8192) g_trace[w_ * 8 + (k)] = __builtin_readcyclecounter();             \
+            const unsigned w_ = wb * (BLOCK / 64) + (threadIdx.x >> 6);              \
+            if (w_ < 8192) g_trace[w_ * 8 + (k)] = wall_clock64();             \
         }                                                                                    \
     } while (0)
 #else
@@ -458,37 +642,73 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 #ifndef QCD_UPD_WAVES
 #define QCD_UPD_WAVES 2   // waves per SIMD the register budget is set for
 #endif
+// everything an update launch needs, as ONE kernel argument: the kernel re-reads it from the
+// kernel-argument segment at the start of every trip of its loop (scalar loads), so that no
+// argument and nothing derived from one has to stay in registers from one site to the next
+struct UpdArgs {
+    double2* U;
+    Geom g;
+    int parity;
+    int nhit;
+    double beta_eff;
+    RlxView rv;
+    const float* gidr;
+    unsigned long long* draws;
+    int nblocks;   // blocks of BLOCK sites in the pass; workgroup b takes b, b + gridDim.x, ...
+    int* redo_list;        // sites whose two-batch window ran dry in this pass (block * BLOCK + thread)
+    unsigned* redo_count;  // their number; zeroed by the redo kernel of the pass before
+    unsigned* redo_count_next;
+};
+
 template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK>
-__global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(double2* __restrict__ U, const Geom g, const int parity,
-                                                  const double beta_eff, const int nhit, const RlxView rv,
-                                                  const float* __restrict__ gidr,
-                                                  unsigned long long* __restrict__ draws)
+__global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs args_by_value)
 {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs the signature only
     __shared__ float rbuf[GID ? 1 : 24 * RLX_WINDOW * BLOCK];
     unsigned long long used = 0;
+    (void)args_by_value;
+    typedef const UpdArgs __attribute__((address_space(4))) * ArgPtr;
+    int wb = blockIdx.x;
+#pragma unroll 1
+    for (;;) {
+    ArgPtr ap = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));   // a fresh, opaque pointer every trip: nothing read through it is carried over
+    if (wb >= ap->nblocks) break;
+    double2* __restrict__ U = ap->U;
+    Geom g;   // member by member: a whole-struct copy out of the argument segment goes through scratch
+    g.nx = ap->g.nx; g.ny = ap->g.ny; g.nz = ap->g.nz; g.nt = ap->g.nt;
+    g.halo = ap->g.halo; g.x0 = ap->g.x0; g.nyh = ap->g.nyh; g.slice_h = ap->g.slice_h;
+    g.vh_int = ap->g.vh_int; g.vh_alloc = ap->g.vh_alloc; g.gsites = ap->g.gsites; g.gslice = ap->g.gslice;
+    g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h;
+    g.tz = ap->g.tz; g.tt = ap->g.tt; g.tx = ap->g.tx;
+    const int parity = ap->parity;
+    const int nhit = ap->nhit;
+    const double beta_eff = ap->beta_eff;
+    RlxView rv;
+    rv.slot0 = ap->rv.slot0; rv.slot1 = ap->rv.slot1; rv.ctl = ap->rv.ctl;
+    rv.ns = ap->rv.ns; rv.q = ap->rv.q; rv.rem = ap->rv.rem;
+    const float* __restrict__ gidr = ap->gidr;
     Site x;
     int t;  // stream number = the site pair's half index in the slab
-#ifdef QCD_STAG_PH  // experiment: de-synchronise the first round of workgroups
-    if (blockIdx.x < 1024) {
-        const int j = blockIdx.x >> 3;
-        const int k = (QCD_STAG_SHIFT < 0 ? ((j * 0x9E3779B1u) >> 20) : (j >> QCD_STAG_SHIFT)) % QCD_STAG_PH;
-        for (int i = 0; i < k * QCD_STAG_SLEEPS; i++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-    if (site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) {
+    if (site_of_workgroup<BLOCK>(g, wb, threadIdx.x, parity, x, t)) {
         const int hb = half_index(g, x) * 16;
+#ifdef QCD_ABL_LOCAL  // diagnostic build: every neighbour is the site itself (minimal traffic, wrong physics)
+        NbrOff nbr;
+        nbr.f0 = nbr.f1 = nbr.f2 = nbr.f3 = nbr.b0 = nbr.b1 = nbr.b2 = nbr.b3 = 0;
+#else
         const NbrOff nbr = neighbour_offsets(g, x);
+#endif
         const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(U, g, DIR, parity);
         RlxFast<BLOCK, NSKIP> rs;
         QCD_STAMP(0);
 #ifdef QCD_TRACE
         if ((threadIdx.x & 63) == 0) {
-            const unsigned w_ = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+            const unsigned w_ = wb * (BLOCK / 64) + (threadIdx.x >> 6);
             if (w_ < 8192) g_trace[w_ * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-            if (w_ < 8192) g_trace[w_ * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
+            if (w_ < 8192) g_trace[w_ * 8 + 7] = __builtin_readcyclecounter();   // shader-clock stamp at start
         }
 #endif
-        mat<GROUP> A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
+        mat<GROUP> A = staple_for_update<GROUP, DIR>(U, g, hb, nbr, parity);
         QCD_STAMP(1);
         mat<GROUP> Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
         if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
@@ -506,24 +726,63 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(double2* __rest
         } else {
             update_link<false>(Ul, A, beta_eff, nhit, rs);
             QCD_STAMP(3);
-            int n = rs.close();
+            const int n = rs.close();
             if (n < 0) {
-                // window ran dry: repeat this link from its old value with the general stream
-                Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
-                RlxStream<BLOCK> slow;
-                slow.open(rv, t, rbuf + threadIdx.x);
-                update_link<false>(Ul, A, beta_eff, nhit, slow);
-                n = slow.close();
+                // window ran dry (many rejected trials): the link and its stream stay as they
+                // were and the site goes on the list that k_update_redo works off after this pass
+                ap->redo_list[atomicAdd(ap->redo_count, 1u)] = wb * BLOCK + (int)threadIdx.x;
+            } else {
+                used += (unsigned long long)n;
+                store_link_buf(r_own, g, hb, Ul);
             }
-            used = (unsigned long long)n;
         }
-        store_link_buf(r_own, g, hb, Ul);
+        if (GID) store_link_buf(r_own, g, hb, Ul);
         QCD_STAMP(4);
+#ifdef QCD_TRACE
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned w_ = wb * (BLOCK / 64) + (threadIdx.x >> 6);
+            if (w_ < 8192) g_trace[w_ * 8 + 5] = __builtin_readcyclecounter();   // shader-clock stamp at end
+        }
+#endif
+    }
+    wb += gridDim.x;
     }
     if (!GID) {
         used = block_sum_u64<BLOCK>(used);
-        if ((threadIdx.x & 63) == 0 && used) atomicAdd(draws, used);
+        if ((threadIdx.x & 63) == 0 && used) atomicAdd(args_by_value.draws, used);
     }
+#endif
+}
+
+// Second kernel of a pass: the sites the first one put on the redo list, each updated from its
+// unchanged link and stream state with the general (refilling) stream.  Sites of one pass do not
+// read each other's links, so doing these after the others gives the same configuration.  Also
+// clears the counter the NEXT pass appends to.  Small fixed grid, grid-stride over the list.
+template <int GROUP, int DIR, int BLOCK, int FAST_BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_update_redo(const UpdArgs a)
+{
+    __shared__ float rbuf[24 * 2 * BLOCK];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.redo_count_next = 0u;
+    const unsigned count = *a.redo_count;
+    unsigned long long used = 0;
+    for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const int w = a.redo_list[i];
+        Site x;
+        int t;
+        if (!site_of_workgroup<FAST_BLOCK>(a.g, w / FAST_BLOCK, w % FAST_BLOCK, a.parity, x, t)) continue;
+        const int hb = half_index(a.g, x) * 16;
+        const NbrOff nbr = neighbour_offsets(a.g, x);
+        const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(a.U, a.g, DIR, a.parity);
+        const mat<GROUP> A = staple<GROUP, DIR>(a.U, a.g, hb, nbr, a.parity);
+        mat<GROUP> Ul = load_link_buf(r_own, a.g, hb, (mat<GROUP>*)nullptr);
+        RlxStream<BLOCK> slow;
+        slow.open(a.rv, t, rbuf + threadIdx.x);
+        update_link<false>(Ul, A, a.beta_eff, a.nhit, slow);
+        used += (unsigned long long)slow.close();
+        store_link_buf(r_own, a.g, hb, Ul);
+    }
+    used = block_sum_u64<BLOCK>(used);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(a.draws, used);
 }
 
 // ---------------------------------------------------------------------------------------------

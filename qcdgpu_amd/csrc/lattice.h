@@ -41,6 +41,9 @@ struct Geom {
     int nzr, ntr;        // regions along z and t
     int rz, rt;          // z and t extent of a region
     int region_h;        // half-sites of a region per x slice = nyh*rz*rt
+    // shape of the block of sites one workgroup updates inside its region: all of y times
+    // tz x tt x tx sites in z, t, x (tz = 0: a run of consecutive half-sites, y then z then t)
+    int tz, tt, tx;
 };
 
 struct Site {
@@ -83,15 +86,33 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
 {
     const int regions = g.nzr * g.ntr;
     const int k = b % regions;
-    const int w = (b / regions) * BLOCK + tid;
-    if (w >= g.nx * g.region_h) return false;
-    s.xs = w / g.region_h;
-    int q = w - s.xs * g.region_h;
-    const int plane = g.nyh * g.rz;
-    const int tl = q / plane;
-    q -= tl * plane;
-    const int zl = q / g.nyh;
-    const int yh = q - zl * g.nyh;
+    int zl, tl, yh;
+    if (g.tz > 0) {
+        // compact block: tiles run z fastest, then t, then x inside the region
+        int T = b / regions;
+        const int ntz = g.rz / g.tz, ntt = g.rt / g.tt;
+        const int Tz = T % ntz;
+        T /= ntz;
+        const int Tt = T % ntt;
+        const int Tx = T / ntt;
+        if (Tx * g.tx >= g.nx) return false;
+        yh = tid % g.nyh;
+        int r = tid / g.nyh;
+        zl = Tz * g.tz + r % g.tz;
+        r /= g.tz;
+        tl = Tt * g.tt + r % g.tt;
+        s.xs = Tx * g.tx + r / g.tt;
+    } else {
+        const int w = (b / regions) * BLOCK + tid;
+        if (w >= g.nx * g.region_h) return false;
+        s.xs = w / g.region_h;
+        int q = w - s.xs * g.region_h;
+        const int plane = g.nyh * g.rz;
+        tl = q / plane;
+        q -= tl * plane;
+        zl = q / g.nyh;
+        yh = q - zl * g.nyh;
+    }
     s.z = (k % g.nzr) * g.rz + zl;
     s.t = (k / g.nzr) * g.rt + tl;
     const int yb = (par + g.x0 + s.xs + s.z + s.t) & 1;

@@ -22,27 +22,21 @@ buf = np.zeros(8192 * 8, dtype=np.uint64)
 rc = lib.qcd_debug_read_trace(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
 assert rc == 0, rc
 t = buf.reshape(8192, 8).astype(np.int64)
+TICK_US = 0.01   # s_memrealtime: 100 MHz, one counter for the whole device
 t0 = t[:, 0].min()
 dur = t[:, 4].max() - t0
-print("us/launch (events, sweep avg) %.1f; stamp span %d ticks" % (1e3 * ms / n, dur))
-tick_us = (1e3 * ms / n) / dur   # rough: one launch = stamp span
-print("tick = %.4f us (if span = launch)" % tick_us)
+print("us/launch (events, sweep avg) %.1f; stamp span %.1f us" % (1e3 * ms / n, dur * TICK_US))
 names = ["staple", "rng", "heatbath", "store"]
 for k in range(4):
-    d = (t[:, k + 1] - t[:, k]) * tick_us
+    d = (t[:, k + 1] - t[:, k]) * TICK_US
     print("%-9s mean %6.2f us  p10 %6.2f  p50 %6.2f  p90 %6.2f" % (names[k], d.mean(), *np.percentile(d, [10, 50, 90])))
-life = (t[:, 4] - t[:, 0]) * tick_us
+life = (t[:, 4] - t[:, 0]) * TICK_US
 print("lifetime  mean %6.2f us  p10 %6.2f  p50 %6.2f  p90 %6.2f" % (life.mean(), *np.percentile(life, [10, 50, 90])))
-start = (t[:, 0] - t0) * tick_us
-print("start-time histogram (us):", np.histogram(start, bins=16)[0].tolist())
-print("start percentiles:", np.percentile(start, [0, 25, 50, 75, 100]).round(1).tolist())
-# concurrency over time: waves in the staple phase vs in ALU phases
-grid = np.linspace(0, dur, 41)[:-1]
-for g in grid[::2]:
-    a = g + t0
-    in_st = ((t[:, 0] <= a) & (a < t[:, 1])).sum()
-    in_alu = ((t[:, 1] <= a) & (a < t[:, 3])).sum()
-    print("t=%6.1f us  staple-phase waves %5d   alu-phase waves %5d" % (g * tick_us, in_st, in_alu))
-hw = t[:, 6]
-print("distinct (cu,simd,se) ids:", len(np.unique(hw & 0xFFFF0)), " xcc ids:", np.unique(t[:, 7]).tolist())
+start = (t[:, 0] - t0) * TICK_US
+print("start-time histogram (10 us bins):", np.histogram(start, bins=np.arange(0, 260, 10))[0].tolist())
+for a in np.arange(0, dur, 5.0 / TICK_US):
+    c = [int(((t[:, k] <= a + t0) & (a + t0 < t[:, k + 1])).sum()) for k in range(4)]
+    print("t=%6.1f us  staple %5d  rng %5d  heatbath %5d  store %4d   resident %5d" % (a * TICK_US, *c, sum(c)))
+clk = (t[:, 5] - t[:, 7]) / ((t[:, 4] - t[:, 0]) * TICK_US)   # shader cycles per us over the wave's life
+print("in-kernel shader clock: median %.0f MHz (p10 %.0f, p90 %.0f)" % (np.median(clk), *np.percentile(clk, [10, 90])))
 np.save(os.path.join(ROOT, "gpurun_out", "trace.npy"), t)
