@@ -48,7 +48,7 @@ int fail(int code, const char* fmt, ...)
 #define QCD_UPD_BLOCK 128
 #endif
 constexpr int UPD_BLOCK = QCD_UPD_BLOCK;
-constexpr int REDO_BLOCK = 64, REDO_GRID = 512;
+constexpr int REDO_BLOCK = 64, REDO_GRID = 128;
 constexpr int MEAS_BLOCK = 256;
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -89,22 +89,41 @@ struct RlxFast {
     int pos, cur;
     bool dry;
 
-    __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
+    // The three steps of opening the stream, separate so that the kernel can place the two
+    // rounds of loads (control word, then state) under other work:
+    // attach: bind the stream and request its control word
+    __device__ __forceinline__ void attach(const RlxView& view, int stream, float* lds_column)
     {
         h.bind(view, stream);
         buf = lds_column;
         dry = false;
         pos = 0;
         cur = (int)(*h.ctl & 1u);
-#ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
-        return;
-#endif
-        RlxRegs r;
+    }
+    // fetch: request the generator state in front of the stream's next batch
+    __device__ __forceinline__ void fetch(RlxRegs& r) const
+    {
+#ifndef QCD_ABL_RNG
         h.load_state(r, cur);
+#endif
+    }
+    // generate: two delivered batches into LDS, the state between them made persistent
+    __device__ __forceinline__ void generate(RlxRegs& r)
+    {
+#ifndef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
+        float* lds_column = const_cast<float*>(buf);
         rlx_batch(r, lds_column, BLOCK);
         skip(r);
         h.store_state(r, cur ^ 1);   // in front of the second batch: the usual next state
         rlx_batch(r, lds_column + 24 * BLOCK, BLOCK);
+#endif
+    }
+    __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
+    {
+        attach(view, stream, lds_column);
+        RlxRegs r;
+        fetch(r);
+        generate(r);
     }
     __device__ __forceinline__ float next()
     {
@@ -577,42 +596,51 @@ __device__ __forceinline__ void second_product(su3& stap, const rows2& p2, const
     reconstruct(r);
     add_to(stap, r);
 }
-template <int DIR, int TERM>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `between` runs after the first product, where the next term's first loads are requested (the
+// last term has none: the caller's own requests take their place)
+template <int DIR, int TERM, class Hook = NoHook>
 __device__ __forceinline__ void pipe_step(su3& stap, raw_pair& ab, raw_link& c, const double2* __restrict__ U,
-                                           const Geom& g, const int hb, const NbrOff& n, const int par)
+                                           const Geom& g, const int hb, const NbrOff& n, const int par,
+                                           Hook between = Hook())
 {
     pin(ab);
     rows2 p = first_product<TERM>(ab);
     pin(p);
     if (TERM < 5) ab = issue_ab<DIR, (TERM < 5 ? TERM + 1 : 5)>(U, g, hb, n, par);
+    between();
     pin(c);
     second_product<TERM>(stap, p, c);
     pin(stap);
     if (TERM < 5) c = issue_c<DIR, (TERM < 5 ? TERM + 1 : 5)>(U, g, hb, n, par);
 }
+// the pipeline in two parts, so that the caller can request what it needs next (its own link,
+// the random stream's state) before the last term's arithmetic
+struct StaplePipe {
+    su3 stap;
+    raw_pair ab;
+    raw_link c;
+};
 template <int DIR>
-__device__ __forceinline__ su3 staple_pipe(const double2* __restrict__ U, const Geom& g, const int hb,
-                                            const NbrOff& n, const int par)
+__device__ __forceinline__ void staple_pipe_head(StaplePipe& sp, const double2* __restrict__ U, const Geom& g,
+                                                 const int hb, const NbrOff& n, const int par)
 {
-    su3 stap = zero<3>();
-    raw_pair ab = issue_ab<DIR, 0>(U, g, hb, n, par);
-    raw_link c = issue_c<DIR, 0>(U, g, hb, n, par);
-    pipe_step<DIR, 0>(stap, ab, c, U, g, hb, n, par);
-    pipe_step<DIR, 1>(stap, ab, c, U, g, hb, n, par);
-    pipe_step<DIR, 2>(stap, ab, c, U, g, hb, n, par);
-    pipe_step<DIR, 3>(stap, ab, c, U, g, hb, n, par);
-    pipe_step<DIR, 4>(stap, ab, c, U, g, hb, n, par);
-    pipe_step<DIR, 5>(stap, ab, c, U, g, hb, n, par);
-    return stap;
+    sp.stap = zero<3>();
+    sp.ab = issue_ab<DIR, 0>(U, g, hb, n, par);
+    sp.c = issue_c<DIR, 0>(U, g, hb, n, par);
+    pipe_step<DIR, 0>(sp.stap, sp.ab, sp.c, U, g, hb, n, par);
+    pipe_step<DIR, 1>(sp.stap, sp.ab, sp.c, U, g, hb, n, par);
+    pipe_step<DIR, 2>(sp.stap, sp.ab, sp.c, U, g, hb, n, par);
+    pipe_step<DIR, 3>(sp.stap, sp.ab, sp.c, U, g, hb, n, par);
+    pipe_step<DIR, 4>(sp.stap, sp.ab, sp.c, U, g, hb, n, par);
 }
-
-template <int GROUP, int DIR>
-__device__ __forceinline__ mat<GROUP> staple_for_update(const double2* __restrict__ U, const Geom& g, const int hb,
-                                                        const NbrOff& n, const int par)
+template <int DIR, class Hook>
+__device__ __forceinline__ void staple_pipe_tail(StaplePipe& sp, const double2* __restrict__ U, const Geom& g,
+                                                 const int hb, const NbrOff& n, const int par, Hook between)
 {
-    if constexpr (GROUP == 3) return staple_pipe<DIR>(U, g, hb, n, par);
-    else
-    return staple<GROUP, DIR>(U, g, hb, n, par);
+    pipe_step<DIR, 5>(sp.stap, sp.ab, sp.c, U, g, hb, n, par, between);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -708,10 +736,30 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             if (w_ < 8192) g_trace[w_ * 8 + 7] = __builtin_readcyclecounter();   // shader-clock stamp at start
         }
 #endif
-        mat<GROUP> A = staple_for_update<GROUP, DIR>(U, g, hb, nbr, parity);
-        QCD_STAMP(1);
-        mat<GROUP> Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
-        if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
+        mat<GROUP> A, Ul;
+        if constexpr (GROUP == 3) {
+            // the stream's control word is requested first, its state and the link itself before
+            // the last staple term is worked out: both round trips are over when the staple is
+            if (!GID) rs.attach(rv, t, rbuf + threadIdx.x);
+            StaplePipe sp;
+            staple_pipe_head<DIR>(sp, U, g, hb, nbr, parity);
+            raw_link own;
+            RlxRegs r;
+            staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, [&]() {
+                own = issue_link(r_own, g, hb);
+                if (!GID) rs.fetch(r);
+            });
+            A = sp.stap;
+            QCD_STAMP(1);
+            pin(own);
+            Ul = as_su3(own);
+            if (!GID) rs.generate(r);
+        } else {
+            A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
+            QCD_STAMP(1);
+            Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
+            if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
+        }
         QCD_STAMP(2);
         if (GID) {
             // table index: site number inside the slab
