@@ -148,6 +148,12 @@ int qcd_timed_sweeps(qcd_ctx *ctx, int n, double *elapsed_ms, unsigned long long
 /* number of random numbers consumed so far by all RANLUX streams of this context */
 int qcd_rng_draws(qcd_ctx *ctx, unsigned long long *draws);
 
+/* PRNG::check (random/random.cpp:339-402): the first `samples` numbers of RANLUX streams
+ * 0 .. streams-1 produced on `device` against the host generator's, value by value;
+ * *errors = how many differ (0 = the device generator reproduces the CPU one) */
+int qcd_prng_check(int device, unsigned rand_series, int lux_level, int streams, int samples,
+                   unsigned *errors);
+
 #ifdef __cplusplus
 }
 #endif

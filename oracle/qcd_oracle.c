@@ -860,6 +860,86 @@ void qo_destroy(qo_lattice *lat)
     free(lat);
 }
 
+/* Hot start, device path only in the reference (the CPU build just prints, sunh.h:114-116).
+ * SU(3): product of three embedded random SU(2) elements, lattice_random3,
+ * SU(N)/suncl/su3_update_cl.cl:164-225 (r[0..3] = rnd1, r[4..7] = rnd2, r[8..11] = rnd3; the .w
+ * lanes are not used); SU(2): lattice_random2, SU(N)/suncl/su2_update_cl.cl:109-146.  Constants
+ * PI, PI2: SU(N)/suncl/model.cl:120-123.  "parity unpinned": no runnable reference for it here. */
+#define QO_PI  3.1415926535897932384626433832795
+#define QO_PI2 6.2831853071795864769252867665590
+void qo_hot_link3(qo_su3 *m, const float r[12])
+{
+    double a0[3], a1[3], a2[3], a3[3];
+    for (int k = 0; k < 3; k++) {
+        const double alpha = QO_PI * (double)r[k];
+        const double phi = QO_PI2 * (double)r[4 + k];
+        const double costh = 2.0 * (double)r[8 + k] - 1.0;
+        const double sinal = sin(alpha);
+        a0[k] = cos(alpha);
+        const double sinph = sin(phi), cosph = cos(phi);
+        const double sinth = sqrt(1.0 - costh * costh);
+        const double t1 = sinal * sinth;
+        a1[k] = t1 * cosph;
+        a2[k] = t1 * sinph;
+        a3[k] = sinal * costh;
+    }
+    enum { x = 0, y = 1, z = 2 };
+    m->u1.re = a0[x] * a0[y] - a3[x] * a3[y];
+    m->u1.im = a0[y] * a3[x] + a0[x] * a3[y];
+    m->u2.re = -a0[x] * a1[y] * a1[z] + a0[z] * a2[x] - a0[x] * a2[y] * a2[z] - a1[z] * a2[y] * a3[x] + a1[y] * a2[z] * a3[x] - a1[x] * a3[z];
+    m->u2.im = a0[z] * a1[x] + a0[x] * a1[z] * a2[y] - a0[x] * a1[y] * a2[z] - a1[y] * a1[z] * a3[x] - a2[y] * a2[z] * a3[x] + a2[x] * a3[z];
+    m->u3.re = -a1[x] * a1[z] + a0[x] * a0[z] * a2[y] + a2[x] * a2[z] - a0[z] * a1[y] * a3[x] + a0[x] * a1[y] * a3[z] + a2[y] * a3[x] * a3[z];
+    m->u3.im = a0[x] * a0[z] * a1[y] + a1[z] * a2[x] + a1[x] * a2[z] + a0[z] * a2[y] * a3[x] - a0[x] * a2[y] * a3[z] + a1[y] * a3[x] * a3[z];
+    m->v3.re = -a0[z] * a1[x] * a1[y] - a0[z] * a2[x] * a2[y] + a0[x] * a2[z] + a1[z] * a3[x] - a1[y] * a2[x] * a3[z] + a1[x] * a2[y] * a3[z];
+    m->v3.im = a0[x] * a1[z] - a0[z] * a1[y] * a2[x] + a0[z] * a1[x] * a2[y] - a2[z] * a3[x] + a1[x] * a1[y] * a3[z] + a2[x] * a2[y] * a3[z];
+    m->v1.re = -a0[y] * a2[x] - a1[x] * a3[y];
+    m->v1.im = a0[y] * a1[x] - a2[x] * a3[y];
+    m->v2.re = a0[x] * a0[z] + a1[y] * a1[z] * a2[x] - a1[x] * a1[z] * a2[y] + a1[x] * a1[y] * a2[z] + a2[x] * a2[y] * a2[z] + a3[x] * a3[z];
+    m->v2.im = -a1[x] * a1[y] * a1[z] - a1[z] * a2[x] * a2[y] + a1[y] * a2[x] * a2[z] - a1[x] * a2[y] * a2[z] - a0[z] * a3[x] + a0[x] * a3[z];
+    reconstruct3(m);
+}
+void qo_hot_link2(qo_su2 *m, const float r[4])
+{
+    const double alpha = QO_PI * (double)r[0];
+    const double phi = QO_PI2 * (double)r[1];
+    const double costh = 2.0 * (double)r[2] - 1.0;
+    const double sinal = sin(alpha);
+    const double a0 = cos(alpha);
+    const double sinph = sin(phi), cosph = cos(phi);
+    const double sinth = sqrt(1.0 - costh * costh);
+    const double t1 = sinal * sinth;
+    const double a1 = t1 * cosph, a2 = t1 * sinph, a3 = sinal * costh;
+    /* uv1 = (a0, a2, a3, a1) = (Re u1, Re u2, Im u1, Im u2) */
+    m->u1.re = a0; m->u1.im = a3;
+    m->u2.re = a2; m->u2.im = a1;
+    /* second row, lattice_reconstruct2, su3_update_cl.cl:112-128 */
+    m->v1.re = -m->u2.re; m->v1.im = m->u2.im;
+    m->v2.re = m->u1.re;  m->v2.im = -m->u1.im;
+}
+
+/* Hot start with per-thread streams: for each direction X, Y, Z, T in turn, stream h opens a
+ * fresh batch of 24; its first 12 values (SU(2): 4) make the link of site 2h, the next 12
+ * (SU(2): 4) that of site 2h+1.  The reference's device path likewise produces one fresh buffer
+ * per direction (SU(N)/suncl/suncl.cpp:5236-5250) and reads float4 k of site gid at
+ * prns[gid + k*ROWSIZE] (SU(N)/suncl/suncl.cl:55-161). */
+static void init_hot_persite(qo_lattice *lat)
+{
+    const int nd = lat->nd, per_link = (lat->group == 3) ? 12 : 4;
+    for (int dir = 0; dir < nd; dir++)
+        for (int h = 0; h < lat->sites / 2; h++) {
+            qo_ranlux *rng = &lat->streams[h];
+            qo_ranlux_align(rng);
+            for (int s = 0; s < 2; s++) {
+                float r[12];
+                for (int k = 0; k < per_link; k++) r[k] = qo_ranlux_next(rng);
+                lat->rng_draws += (unsigned long long)per_link;
+                const int gid = 2 * h + s;
+                if (lat->group == 3) qo_hot_link3(&((qo_su3 *)lat->links)[gid * nd + dir], r);
+                else qo_hot_link2(&((qo_su2 *)lat->links)[gid * nd + dir], r);
+            }
+        }
+}
+
 void qo_init_links(qo_lattice *lat)
 {
     /* lattice_initializeCPU, sunh.h:111-131.  ints == 0 (hot) only prints in the reference
@@ -870,6 +950,8 @@ void qo_init_links(qo_lattice *lat)
             if (lat->group == 3) unity3(&((qo_su3 *)lat->links)[i]);
             else unity2(&((qo_su2 *)lat->links)[i]);
         }
+    } else if (lat->ints == 0 && lat->rng_mode == QO_RNG_PERSITE) {
+        init_hot_persite(lat);
     } else if (lat->ints == 2) {
         for (int gid = 0; gid < lat->sites; gid++)
             for (int dir = 0; dir < nd; dir++) {

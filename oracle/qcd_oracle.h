@@ -46,7 +46,7 @@ typedef struct {
     int sites;
     int nhit;
     double beta;
-    int ints;             /* 0 hot (unusable on the CPU path), 1 cold, 2 gid */
+    int ints;             /* 0 hot (per-thread streams only; the reference's CPU path has none), 1 cold, 2 gid */
     int rng_mode;         /* QO_RNG_* */
     int nskip;            /* luxury skip: 24/48/97/223/389 */
     unsigned randseries;
@@ -83,6 +83,9 @@ void   qo_matrix_gid3(qo_su3 *a, int gid, int dir, int sites);
 qo_su2 qo_mul2(const qo_su2 *a, const qo_su2 *b);
 qo_su2 qo_herm2(const qo_su2 *a);
 void   qo_matrix_gid2(qo_su2 *a, int gid, int dir, int sites);
+/* hot-start links from 12 / 4 uniform numbers (device path of the reference only; "parity unpinned") */
+void   qo_hot_link3(qo_su3 *m, const float r[12]);
+void   qo_hot_link2(qo_su2 *m, const float r[4]);
 
 /* lattice life cycle */
 qo_lattice *qo_create(int group, const int L[4], double beta, int nhit, int ints,

@@ -157,6 +157,13 @@ class BigLattice:
         self.beta = beta
         self.sites = int(np.prod(L))
 
+    def fill_halos(self):
+        """Every halo slice from its owner (needed once after a hot start: cold and gid starts
+        fill their halos from closed forms)."""
+        for d in (X, Y, Z, T):
+            for parity in (0, 1):
+                self.comm.exchange(d, parity)
+
     def update(self, parity: int, direction: int):
         for e in self.engines:
             e.update(parity, direction)
@@ -205,7 +212,10 @@ def make_gpu_slabs(group, L, beta, nx_parts: Sequence[int], device_index: int = 
         ctx.init_lattice()
         engines.append(LocalGpuEngine(ctx))
         x0 += nx
-    return BigLattice(engines, LocalComm(engines), group, L, beta)
+    lat = BigLattice(engines, LocalComm(engines), group, L, beta)
+    if ctx_kw.get("start_mode") == capi.START_HOT:
+        lat.fill_halos()
+    return lat
 
 
 class LocalGpuEngine:
@@ -245,4 +255,7 @@ def make_rank_slab(group, L, beta, rank: int, world: int, device_index: int, dis
                        nx_local=parts[rank], halo=1, **ctx_kw)
     ctx.init_lattice()
     eng = GpuSlabEngine(ctx, device_index)
-    return BigLattice([eng], TorchDistComm(eng, rank, world, dist_group), group, L, beta)
+    lat = BigLattice([eng], TorchDistComm(eng, rank, world, dist_group), group, L, beta)
+    if ctx_kw.get("start_mode") == capi.START_HOT:
+        lat.fill_halos()
+    return lat

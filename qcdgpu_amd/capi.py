@@ -41,7 +41,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums", "qcd_upload", "qcd_download",
            "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
-           "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws"]
+           "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check"]
 
 
 def _load():
@@ -88,6 +88,7 @@ def _load():
     lib.qcd_rng_draws.argtypes = [P, C.POINTER(C.c_ulonglong)]
     # host-only helpers (no device needed)
     lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
+    lib.qcd_prng_check.argtypes = [I, C.c_uint, I, I, I, C.POINTER(C.c_uint)]
     lib.qcd_host_gid_link.argtypes = [I, I, I, I, pd]
     lib.qcd_host_gid_randoms.argtypes = [I, I, I, C.POINTER(C.c_float)]
     return lib
@@ -217,6 +218,14 @@ class Context:
         d = C.c_ulonglong()
         _check(lib.qcd_rng_draws(self.h, C.byref(d)))
         return d.value
+
+
+def prng_check(device=0, rand_series=54, lux_level=3, streams=256, samples=240):
+    """Device RANLUX against the host generator (the reference's PRNG::check); returns the
+    number of values that differ."""
+    bad = C.c_uint()
+    _check(lib.qcd_prng_check(device, rand_series, lux_level, streams, samples, C.byref(bad)))
+    return bad.value
 
 
 def host_ranlux_stream(rand_series, stream, lux_level, n):

@@ -359,8 +359,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     if (p->nhit < 1) return fail(QCD_ERR_INVALID, "NHIT = %d < 1", p->nhit);
     if (p->lux_level < 0 || p->lux_level > 4) return fail(QCD_ERR_INVALID, "RANLUX level %d not in 0..4", p->lux_level);
     if (p->rand_series == 0) return fail(QCD_ERR_INVALID, "RANDSERIES = 0 (time seed) must be resolved by the host");
-    if (p->start_mode != QCD_START_COLD && p->start_mode != QCD_START_GID)
-        return fail(QCD_ERR_UNSUPPORTED, "start mode %d: only cold (1) and gid (2) starts are implemented", p->start_mode);
+    if (p->start_mode != QCD_START_HOT && p->start_mode != QCD_START_COLD && p->start_mode != QCD_START_GID)
+        return fail(QCD_ERR_INVALID, "start mode %d is not hot (0), cold (1) or gid (2)", p->start_mode);
     if (p->nx_local < 1 || p->x0 < 0 || p->x0 + p->nx_local > p->L[0])
         return fail(QCD_ERR_INVALID, "slab [%d, %d) outside 0..%d", p->x0, p->x0 + p->nx_local, p->L[0]);
     if (p->halo != 0 && p->halo != 1) return fail(QCD_ERR_INVALID, "halo must be 0 or 1");
@@ -530,7 +530,9 @@ int qcd_init_lattice(qcd_ctx* c)
     int rc = check_ctx(c, false);
     if (rc) return rc;
     const Geom& g = c->g;
-    if (c->p.start_mode == QCD_START_COLD) {
+    if (c->p.start_mode == QCD_START_COLD || c->p.start_mode == QCD_START_HOT) {
+        // hot start: unit links first, so that the halo slices of a slab hold group elements
+        // until the first exchange brings the neighbours' links
         const dim3 grid(cdiv((long)c->U_elems, MEAS_BLOCK) > 4096 ? 4096 : cdiv((long)c->U_elems, MEAS_BLOCK)), block(MEAS_BLOCK);
         if (c->p.group == 3) hipLaunchKernelGGL((k_init_cold<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g);
         else hipLaunchKernelGGL((k_init_cold<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g);
@@ -552,6 +554,14 @@ int qcd_init_lattice(qcd_ctx* c)
     }
     rc = seed_streams(c);
     if (rc) return rc;
+    if (c->p.start_mode == QCD_START_HOT) {
+        const dim3 grid(cdiv((long)g.vh_int, MEAS_BLOCK)), block(MEAS_BLOCK);
+        if (c->p.group == 3) hipLaunchKernelGGL((k_init_hot<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, c->rv, c->draws_dev);
+        else hipLaunchKernelGGL((k_init_hot<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, c->rv, c->draws_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    // the caller may switch streams right after this call: leave nothing in flight
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->initialized = true;
     return QCD_OK;
 }
@@ -851,6 +861,65 @@ int qcd_rng_draws(qcd_ctx* c, unsigned long long* draws)
 }
 
 // ---- host-only helpers exported for the CPU test-suite (no device needed) -------------------
+
+// Generator self-check, the counterpart of PRNG::check (SU(N)/random/random.cpp:339-402): the
+// first `samples` numbers of streams 0 .. streams-1 produced on the device are compared, bit for
+// bit, with the host generator's.  *errors = number of values that differ.
+int qcd_prng_check(int device, unsigned rand_series, int lux_level, int streams, int samples, unsigned* errors)
+{
+    if (!errors || streams < 1 || samples < 1 || lux_level < 0 || lux_level > 4 || rand_series == 0)
+        return fail(QCD_ERR_INVALID, "bad arguments");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(QCD_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    const int nskip = rlx_nskip_for_level(lux_level);
+    const int batches = (samples + 23) / 24;
+    const int ns = streams;
+    std::vector<int> seeds = stream_seeds(rand_series, 0, ns);
+    std::vector<unsigned> st((size_t)RLX_STATE_WORDS * ns);
+    std::vector<RlxRegs> regs((size_t)ns);
+    for (int i = 0; i < ns; i++) {
+        rlx_seed_state(seeds[(size_t)i], nskip, regs[(size_t)i]);
+        for (int w = 0; w < 24; w++) st[(size_t)w * ns + i] = regs[(size_t)i].s[w];
+        st[(size_t)24 * ns + i] = regs[(size_t)i].c;
+    }
+    unsigned* d_state = nullptr;
+    float* d_out = nullptr;
+    const size_t nout = (size_t)24 * batches * ns;
+    HIP_TRY(hipMalloc(&d_state, st.size() * sizeof(unsigned)));
+    hipError_t e = hipMalloc(&d_out, nout * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(d_state);
+        return fail(QCD_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    std::vector<float> got(nout);
+    e = hipMemcpy(d_state, st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_rlx_dump<MEAS_BLOCK>), dim3(cdiv((long)ns, MEAS_BLOCK)), dim3(MEAS_BLOCK), 0, 0, d_state, ns,
+                           nskip / 24, nskip % 24, batches, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(got.data(), d_out, nout * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_state);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(QCD_ERR_HIP, "generator check: %s", hipGetErrorString(e));
+    unsigned bad = 0;
+    for (int i = 0; i < ns; i++) {
+        RlxRegs r = regs[(size_t)i];
+        float batch[24];
+        for (int b = 0; b < batches; b++) {
+            rlx_batch(r, batch, 1);
+            rlx_skip(r, nskip / 24, nskip % 24);
+            for (int k = 0; k < 24 && 24 * b + k < samples; k++) {
+                const float d = got[((size_t)24 * b + k) * ns + i];
+                if (memcmp(&d, &batch[k], sizeof(float)) != 0) bad++;
+            }
+        }
+    }
+    *errors = bad;
+    return QCD_OK;
+}
 
 // n values of stream `stream` produced by the batch formulation the kernels use
 int qcd_host_ranlux_stream(unsigned rand_series, int stream, int lux_level, int n, float* out)

@@ -364,6 +364,10 @@ void model::lattice_simulate(void)
     free(timestart);
     timestart = current_datetime(&ltimestart);
     for (auto& s : SubLat) check(qcd_init_lattice(s.ctx), "qcd_init_lattice");
+    // hot start: a part's halo slices hold its neighbours' random links only after an exchange
+    if (ints == model_start_hot)
+        for (int dir = 0; dir < 4; dir++)
+            for (int parity = 0; parity < 2; parity++) UpdateEdges(dir, parity);
     int ITER_counter = 0;
     measure(ITER_counter++);
     for (int i = 0; i < NAV; i++) {

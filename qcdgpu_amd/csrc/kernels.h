@@ -995,6 +995,120 @@ __global__ __launch_bounds__(BLOCK) void k_init_cold(double2* __restrict__ U, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// hot start (kernels lattice_init_hot_{X,Y,Z,T}, SU(N)/suncl/suncl.cl:55-161): every link a
+// random group element made from uniform numbers -- SU(3): product of three embedded SU(2)
+// elements (lattice_random3, SU(N)/suncl/su3_update_cl.cl:164-225), SU(2): lattice_random2
+// (SU(N)/suncl/su2_update_cl.cl:109-146).  The reference produces a fresh random buffer per
+// direction (SU(N)/suncl/suncl.cpp:5236-5250); here stream h opens a fresh batch of 24 per
+// direction, values 0..11 (SU(2): 0..3) for site 2h and 12..23 (SU(2): 4..7) for site 2h+1.
+
+#define QCD_PI 3.1415926535897932384626433832795   // SU(N)/suncl/model.cl:120-123
+#define QCD_PI2 6.2831853071795864769252867665590
+
+__device__ __forceinline__ void hot_su2_angles(float r_alpha, float r_phi, float r_costh, double& a0, double& a1,
+                                               double& a2, double& a3)
+{
+    const double alpha = QCD_PI * (double)r_alpha;
+    const double phi = QCD_PI2 * (double)r_phi;
+    const double costh = 2.0 * (double)r_costh - 1.0;
+    const double sinal = sin(alpha);
+    a0 = cos(alpha);
+    const double sinph = sin(phi), cosph = cos(phi);
+    const double sinth = sqrt(1.0 - costh * costh);
+    const double t1 = sinal * sinth;
+    a1 = t1 * cosph;
+    a2 = t1 * sinph;
+    a3 = sinal * costh;
+}
+// r: 12 values, r[k * stride]
+__device__ __forceinline__ su3 hot_link(const float* r, int stride, su3*)
+{
+    double a0[3], a1[3], a2[3], a3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) hot_su2_angles(r[k * stride], r[(4 + k) * stride], r[(8 + k) * stride], a0[k], a1[k], a2[k], a3[k]);
+    constexpr int x = 0, y = 1, z = 2;
+    su3 m;
+    m.e[0][0] = mk(a0[x] * a0[y] - a3[x] * a3[y], a0[y] * a3[x] + a0[x] * a3[y]);
+    m.e[0][1] = mk(-a0[x] * a1[y] * a1[z] + a0[z] * a2[x] - a0[x] * a2[y] * a2[z] - a1[z] * a2[y] * a3[x] + a1[y] * a2[z] * a3[x] - a1[x] * a3[z],
+                   a0[z] * a1[x] + a0[x] * a1[z] * a2[y] - a0[x] * a1[y] * a2[z] - a1[y] * a1[z] * a3[x] - a2[y] * a2[z] * a3[x] + a2[x] * a3[z]);
+    m.e[0][2] = mk(-a1[x] * a1[z] + a0[x] * a0[z] * a2[y] + a2[x] * a2[z] - a0[z] * a1[y] * a3[x] + a0[x] * a1[y] * a3[z] + a2[y] * a3[x] * a3[z],
+                   a0[x] * a0[z] * a1[y] + a1[z] * a2[x] + a1[x] * a2[z] + a0[z] * a2[y] * a3[x] - a0[x] * a2[y] * a3[z] + a1[y] * a3[x] * a3[z]);
+    m.e[1][0] = mk(-a0[y] * a2[x] - a1[x] * a3[y], a0[y] * a1[x] - a2[x] * a3[y]);
+    m.e[1][1] = mk(a0[x] * a0[z] + a1[y] * a1[z] * a2[x] - a1[x] * a1[z] * a2[y] + a1[x] * a1[y] * a2[z] + a2[x] * a2[y] * a2[z] + a3[x] * a3[z],
+                   -a1[x] * a1[y] * a1[z] - a1[z] * a2[x] * a2[y] + a1[y] * a2[x] * a2[z] - a1[x] * a2[y] * a2[z] - a0[z] * a3[x] + a0[x] * a3[z]);
+    m.e[1][2] = mk(-a0[z] * a1[x] * a1[y] - a0[z] * a2[x] * a2[y] + a0[x] * a2[z] + a1[z] * a3[x] - a1[y] * a2[x] * a3[z] + a1[x] * a2[y] * a3[z],
+                   a0[x] * a1[z] - a0[z] * a1[y] * a2[x] + a0[z] * a1[x] * a2[y] - a2[z] * a3[x] + a1[x] * a1[y] * a3[z] + a2[x] * a2[y] * a3[z]);
+    reconstruct(m);
+    return m;
+}
+// r: 4 values (the fourth is not used, as in the reference)
+__device__ __forceinline__ su2 hot_link(const float* r, int stride, su2*)
+{
+    double a0, a1, a2, a3;
+    hot_su2_angles(r[0], r[stride], r[2 * stride], a0, a1, a2, a3);
+    su2 m;
+    m.e[0][0] = mk(a0, a3);   // uv1 = (a0, a2, a3, a1) = (Re u1, Re u2, Im u1, Im u2)
+    m.e[0][1] = mk(a2, a1);
+    reconstruct(m);
+    return m;
+}
+
+template <int GROUP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_init_hot(double2* __restrict__ U, const Geom g, const RlxView rv,
+                                                    unsigned long long* __restrict__ draws)
+{
+    __shared__ float rbuf[24 * BLOCK];
+    constexpr int PER_LINK = (GROUP == 3) ? 12 : 4;
+    const int t = blockIdx.x * BLOCK + threadIdx.x;   // stream = owned half-site index
+    unsigned long long used = 0;
+    if (t < g.vh_int) {
+        Site s0 = site_of(g, t, 0);                    // the pair's site of parity 0 ...
+        Site s1 = s0;
+        s1.y ^= 1;                                     // ... and its partner in y, of parity 1
+        const int h = half_index(g, s0);
+        const bool even_first = (s0.y & 1) == 0;       // site 2h is the one with even y
+        RlxHome home;
+        home.bind(rv, t);
+        const int cur = (int)(*home.ctl & 1u);
+        RlxRegs r;
+        home.load_state(r, cur);
+        float* col = rbuf + threadIdx.x;
+#pragma unroll 1
+        for (int dir = 0; dir < 4; dir++) {
+            rlx_batch(r, col, BLOCK);
+            rlx_skip(r, home.q, home.rem);
+            const mat<GROUP> a = hot_link(col, BLOCK, (mat<GROUP>*)nullptr);                     // site 2h
+            const mat<GROUP> b = hot_link(col + PER_LINK * BLOCK, BLOCK, (mat<GROUP>*)nullptr);  // site 2h+1
+            store_link(U, g, dir, 0, h, even_first ? a : b);
+            store_link(U, g, dir, 1, h, even_first ? b : a);
+            used += 2 * PER_LINK;
+        }
+        home.store_state(r, cur);   // in front of the stream's next batch; the control word stays
+    }
+    used = block_sum_u64<BLOCK>(used);
+    if ((threadIdx.x & 63) == 0 && used) atomicAdd(draws, used);
+}
+
+// ---------------------------------------------------------------------------------------------
+// generator self-check (PRNG::check, SU(N)/random/random.cpp:339-402: device numbers against the
+// CPU generator's, value by value): stream i delivers `batches` batches into out[(24 b + k) * ns + i]
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rlx_dump(const unsigned* __restrict__ state, const int ns, const int q,
+                                                    const int rem, const int batches, float* __restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= ns) return;
+    RlxRegs r;
+#pragma unroll
+    for (int w = 0; w < 24; w++) r.s[w] = state[(size_t)w * ns + i];
+    r.c = state[(size_t)24 * ns + i];
+    for (int b = 0; b < batches; b++) {
+        rlx_batch(r, out + (size_t)24 * b * ns + i, ns);
+        rlx_skip(r, q, rem);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // reference device layout <-> engine layout.  `table` holds `nslices` x-slices starting at
 // stored slice `slice0` (0 = left halo of a slab, or the first owned slice when halo = 0):
 // rows of double4, element [lg + row*rowsize], lg = y + z*Ny + t*Ny*Nz + xl*Ny*Nz*Nt.

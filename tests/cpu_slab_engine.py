@@ -28,7 +28,9 @@ class CpuSlabEngine:
         # [x][site in slice][dir][reals]
         self.links = np.frombuffer(buf, dtype=np.float64).reshape(L[0], self.slice, 4, reals)
         owned = np.zeros(L[0], dtype=bool)
-        for x in range(x0 - 1, x0 + nx + 1):
+        # hot start: the halos too are unknown until BigLattice.fill_halos() has run
+        pad = 0 if ints == 0 else 1
+        for x in range(x0 - pad, x0 + nx + pad):
             owned[x % L[0]] = True
         self.links[~owned] = np.nan
         c = np.arange(self.slice)

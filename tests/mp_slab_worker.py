@@ -22,6 +22,8 @@ def main():
     eng = CpuSlabEngine(cfg["group"], L, cfg["beta"], x0, parts[rank], nhit=cfg["nhit"], seed=cfg["seed"],
                         ints=cfg["ints"])
     lat = bl.BigLattice([eng], bl.TorchDistComm(eng, rank, world), cfg["group"], L, cfg["beta"])
+    if cfg["ints"] == 0:
+        lat.fill_halos()
     rows = [np.concatenate([lat.plaquette(), lat.action(), lat.polyakov()]).tolist()]
     for _ in range(cfg["sweeps"]):
         lat.sweep(1)

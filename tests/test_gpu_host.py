@@ -74,6 +74,23 @@ def test_cli_biglattice_equals_single_lattice(tmp_path):
     lat.close()
 
 
+def test_cli_hot_start_single_and_biglattice(tmp_path):
+    """INTS = 0 through the host shell: sample 0 is a random configuration (plaquette ~ 0), and
+    the run is the same whether the lattice is cut into parts or not."""
+    keys = dict(GROUP=3, ND=4, L1=8, L2=6, L3=4, L4=6, BETA=5.9, NHIT=6, INTS=0, PRNG="RANLUX3",
+                RANDSERIES=31, NAV=1, ITER=3, NITER=1)
+    text, _, single, _ = _run(tmp_path / "a", keys)
+    _, _, two, _ = _run(tmp_path / "b", keys, "\tN1 = {2, 6}\n\tDEVICE = {0, 0}\n")
+    assert " ints (0=hot, 1=cold, 2=gid) : 0" in text
+    assert abs(single[0, 2]) < 0.1 and single[2, 2] > 0.5
+    assert np.max(np.abs(two - single)) < 1e-13
+    lat = ol.Lattice(3, (8, 6, 4, 6), 5.9, nhit=6, ints=0, rng_mode=ol.RNG_PERSITE, seed=31)
+    assert np.max(np.abs(single[0, :3] - lat.plaquette())) < 1e-13
+    lat.sweep(2)
+    assert np.max(np.abs(single[1, :3] - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-11
+    lat.close()
+
+
 def test_biglattice_python_driver_on_one_gpu():
     """Several slabs on one device through the pack/unpack halves of UpdateEdges."""
     import qcdgpu_amd as q
@@ -90,6 +107,22 @@ def test_biglattice_python_driver_on_one_gpu():
         draws = sum(e.ctx.rng_draws() for e in big.engines)
         assert draws == ol.rng_draws(lat)
         lat.close()
+
+
+def test_hot_start_biglattice_equals_single_lattice():
+    """Hot start cut into slabs: halos come from the neighbours' streams through one exchange."""
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    L = (8, 4, 4, 6)
+    lat = ol.Lattice(3, L, 5.9, nhit=4, ints=0, rng_mode=ol.RNG_PERSITE, seed=3)
+    big = bl.make_gpu_slabs(3, L, 5.9, [4, 2, 2], nhit=4, rand_series=3, start_mode=q.START_HOT)
+    assert np.max(np.abs(big.plaquette() - lat.plaquette())) < 1e-13
+    for s in range(2):
+        big.sweep(1)
+        lat.sweep(1)
+        assert np.max(np.abs(big.plaquette() - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-11
+    assert sum(e.ctx.rng_draws() for e in big.engines) == ol.rng_draws(lat)
+    lat.close()
 
 
 def test_gid_biglattice_matches_reference_vector():

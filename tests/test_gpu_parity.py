@@ -130,6 +130,43 @@ def test_ranlux_runs_match_checker(group, L, beta, nhit, lux, seed):
     lat.close()
 
 
+@pytest.mark.parametrize("group,L,beta", [(3, (8, 6, 4, 8), 5.8), (2, (6, 8, 6, 4), 2.4)])
+def test_hot_start_matches_checker(group, L, beta):
+    """Hot start (the reference has it on the device path only: parity unpinned).  The checker
+    restates lattice_random3 / lattice_random2 with the same per-thread streams; sin/cos come
+    from different libms, so links agree to rounding, not bit for bit."""
+    import qcdgpu_amd as q
+    lat = ol.Lattice(group, L, beta, nhit=10, ints=0, rng_mode=ol.RNG_PERSITE, seed=11)
+    with _ctx(group=group, L=L, beta=beta, nhit=10, start_mode=q.START_HOT, rand_series=11) as c:
+        c.init_lattice()
+        assert c.rng_draws() == ol.rng_draws(lat)
+        got, want = c.download(), lat.export_table()
+        assert np.max(np.abs(got - want)) < 1e-14
+        assert abs(c.plaquette()[2]) < 0.1                 # random links: plaquette ~ 0
+        assert np.max(np.abs(c.plaquette() - lat.plaquette())) < 1e-13
+        for sweep in range(2):                             # streams resume in front of a fresh batch
+            c.sweep(1)
+            lat.sweep(1)
+            assert c.rng_draws() == ol.rng_draws(lat), sweep
+            assert _rel(c.plaquette(), lat.plaquette()) < 1e-11, sweep
+    lat.close()
+
+
+@pytest.mark.parametrize("lux", [0, 1, 2, 3, 4])
+def test_device_generator_reproduces_cpu_generator(lux):
+    """The reference's own PRNG known-answer test (PRNG::check): device stream against the CPU
+    generator, value by value -- here for many streams and against the checker as well."""
+    import ctypes as C
+    import qcdgpu_amd as q
+    assert q.prng_check(device=0, rand_series=54, lux_level=lux, streams=300, samples=250) == 0
+    # and the host generator the check compares with is the checker's (stream 0 and a later one)
+    for stream in (0, 17):
+        st = ol.RanluxState()
+        ol.lib.qo_ranlux_init(C.byref(st), ol.lib.qo_stream_jseed(54, stream), ol.lib.qo_nskip_for_level(lux))
+        want = np.array([ol.lib.qo_ranlux_next(C.byref(st)) for _ in range(100)], dtype=np.float32)
+        assert np.array_equal(q.host_ranlux_stream(54, stream, lux, 100), want)
+
+
 def test_config1_su3_16_plaquette_vs_cpu():
     """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)
@@ -171,7 +208,7 @@ def test_errors_are_status_codes_not_exits():
     with pytest.raises(q.QcdError):
         _ctx(group=3, L=(4, 5, 4, 4), beta=1.0)          # odd Ny
     with pytest.raises(q.QcdError):
-        _ctx(group=3, L=(4, 4, 4, 4), beta=1.0, start_mode=q.START_HOT)
+        _ctx(group=3, L=(4, 4, 4, 4), beta=1.0, start_mode=7)
     with _ctx(group=3, L=(4, 4, 4, 4), beta=1.0) as c:
         with pytest.raises(q.QcdError):
             c.sweep(1)                                    # before init

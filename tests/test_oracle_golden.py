@@ -73,6 +73,33 @@ def test_cold_start_known_answers():
         lat.close()
 
 
+def test_hot_start_links_are_group_elements():
+    """Hot start (restated from the reference's device kernels; no runnable reference: parity
+    unpinned): unitary, unit determinant, plaquette near zero, reproducible from the seed."""
+    for group in (2, 3):
+        a = ol.Lattice(group, (4, 4, 4, 6), 5.0, ints=0, rng_mode=ol.RNG_PERSITE, seed=5)
+        b = ol.Lattice(group, (4, 4, 4, 6), 5.0, ints=0, rng_mode=ol.RNG_PERSITE, seed=5)
+        c = ol.Lattice(group, (4, 4, 4, 6), 5.0, ints=0, rng_mode=ol.RNG_PERSITE, seed=6)
+        ta, tb, tc = a.export_table(), b.export_table(), c.export_table()
+        assert np.array_equal(ta, tb) and not np.array_equal(ta, tc)
+        assert ol.rng_draws(a) == a.sites * 4 * (12 if group == 3 else 4)
+        assert abs(a.plaquette()[2]) < 0.15
+        if group == 3:
+            # rows of the 12-real storage: u = (uv1.xyz + i uv2.xyz), v = (uv3.xy, uv1.w) + i (uv3.zw, uv2.w)
+            for d in range(4):
+                u = ta[0 * 4 + d, :, :3] + 1j * ta[1 * 4 + d, :, :3]
+                v = np.stack([ta[2 * 4 + d, :, 0] + 1j * ta[2 * 4 + d, :, 2],
+                              ta[2 * 4 + d, :, 1] + 1j * ta[2 * 4 + d, :, 3],
+                              ta[0 * 4 + d, :, 3] + 1j * ta[1 * 4 + d, :, 3]], axis=1)
+                assert np.max(np.abs(np.sum(np.abs(u) ** 2, axis=1) - 1)) < 1e-14
+                assert np.max(np.abs(np.sum(np.abs(v) ** 2, axis=1) - 1)) < 1e-14
+                assert np.max(np.abs(np.sum(u * np.conj(v), axis=1))) < 1e-14
+        else:
+            assert np.max(np.abs(np.sum(ta ** 2, axis=2) - 1)) < 1e-14
+        for l in (a, b, c):
+            l.close()
+
+
 def test_device_layout_roundtrip():
     for group in (2, 3):
         lat = ol.Lattice(group, (4, 4, 6, 4), 5.0, ints=2, rng_mode=ol.RNG_GID)
