@@ -117,6 +117,15 @@ int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
 int qcd_upload(qcd_ctx *ctx, const void *host_table, size_t bytes, int rowsize);
 int qcd_download(qcd_ctx *ctx, void *host_table, size_t bytes, int rowsize);
 
+/* generator part of lattice_save_state / lattice_load_state (suncl.cpp:1857-2079).  The reference
+ * restores its generator by replaying PRNG0->produce() PRNG_counter times (suncl.cpp:5349-5351);
+ * per-thread streams are saved instead: [draws u64][ctl ns][slot0 25*ns][slot1 25*ns], 32-bit
+ * words, ns = owned half-sites, the slots in word-major order [w][stream].  Upload after
+ * qcd_upload or qcd_init_lattice. */
+size_t qcd_rng_state_bytes(const qcd_ctx *ctx);
+int qcd_rng_state_download(qcd_ctx *ctx, void *host, size_t bytes);
+int qcd_rng_state_upload(qcd_ctx *ctx, const void *host, size_t bytes);
+
 /* model::UpdateEdges(dir) (suncl.cpp:4005-4061), split into its two halves so that the transport
  * between contexts (peer copy, RCCL send/recv) is the caller's.  A message carries the links of
  * ONE direction on the sites of ONE parity of one boundary x-slice:

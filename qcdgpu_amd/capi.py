@@ -41,7 +41,8 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums", "qcd_upload", "qcd_download",
            "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
-           "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check"]
+           "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
+           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload"]
 
 
 def _load():
@@ -89,6 +90,10 @@ def _load():
     # host-only helpers (no device needed)
     lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
     lib.qcd_prng_check.argtypes = [I, C.c_uint, I, I, I, C.POINTER(C.c_uint)]
+    lib.qcd_rng_state_bytes.restype = C.c_size_t
+    lib.qcd_rng_state_bytes.argtypes = [P]
+    lib.qcd_rng_state_download.argtypes = [P, C.c_void_p, C.c_size_t]
+    lib.qcd_rng_state_upload.argtypes = [P, C.c_void_p, C.c_size_t]
     lib.qcd_host_gid_link.argtypes = [I, I, I, I, pd]
     lib.qcd_host_gid_randoms.argtypes = [I, I, I, C.POINTER(C.c_float)]
     return lib
@@ -213,6 +218,17 @@ class Context:
         launches = C.c_ulonglong()
         _check(lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
         return ms.value, launches.value
+
+    def rng_state(self):
+        """The RANLUX streams' state as bytes (for checkpoints)."""
+        n = lib.qcd_rng_state_bytes(self.h)
+        buf = np.empty(n, dtype=np.uint8)
+        _check(lib.qcd_rng_state_download(self.h, buf.ctypes.data_as(C.c_void_p), n))
+        return buf
+
+    def set_rng_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        _check(lib.qcd_rng_state_upload(self.h, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
 
     def rng_draws(self):
         d = C.c_ulonglong()

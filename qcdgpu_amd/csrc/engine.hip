@@ -716,6 +716,42 @@ int qcd_download(qcd_ctx* c, void* host_table, size_t bytes, int rowsize)
     return transfer(c, host_table, bytes, rowsize, false);
 }
 
+// State of this context's RANLUX streams, for checkpoints: [draws u64][ctl ns][slot0 25*ns]
+// [slot1 25*ns] (32-bit words; the two slots in word-major order [w][stream]).  The reference
+// restores its generator by replaying produce() PRNG_counter times (SU(N)/suncl/suncl.cpp:5349-5351);
+// per-thread streams are saved instead.
+size_t qcd_rng_state_bytes(const qcd_ctx* c)
+{
+    if (!c) return 0;
+    return sizeof(unsigned long long) + (size_t)(2 * RLX_STATE_WORDS + 1) * c->g.vh_int * sizeof(unsigned);
+}
+
+static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (!host) return fail(QCD_ERR_INVALID, "null buffer");
+    if (bytes != qcd_rng_state_bytes(c)) return fail(QCD_ERR_INVALID, "generator state is %zu bytes, got %zu", qcd_rng_state_bytes(c), bytes);
+    const size_t ns = (size_t)c->g.vh_int, sw = (size_t)RLX_STATE_WORDS * ns * sizeof(unsigned);
+    char* h = (char*)host;
+    const hipMemcpyKind kind = up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    auto cp = [&](void* dev, char* hp, size_t n) -> hipError_t {
+        return up ? hipMemcpyAsync(dev, hp, n, kind, c->stream) : hipMemcpyAsync(hp, dev, n, kind, c->stream);
+    };
+    HIP_TRY(cp(c->draws_dev, h, sizeof(unsigned long long)));
+    h += sizeof(unsigned long long);
+    HIP_TRY(cp(c->rv.ctl, h, ns * sizeof(unsigned)));
+    h += ns * sizeof(unsigned);
+    HIP_TRY(cp(c->rv.slot0, h, sw));
+    h += sw;
+    HIP_TRY(cp(c->rv.slot1, h, sw));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QCD_OK;
+}
+
+int qcd_rng_state_download(qcd_ctx* c, void* host, size_t bytes) { return rng_state_copy(c, host, bytes, false); }
+int qcd_rng_state_upload(qcd_ctx* c, const void* host, size_t bytes) { return rng_state_copy(c, const_cast<void*>(host), bytes, true); }
+
 size_t qcd_halo_bytes(const qcd_ctx* c)
 {
     if (!c) return 0;

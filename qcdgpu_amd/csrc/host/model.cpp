@@ -249,6 +249,7 @@ static char* current_datetime(time_t* t)
 // lattice_init (SU(N)/suncl/suncl.cpp:618-706): device selection and buffers; one context per part
 void model::lattice_init(void)
 {
+    if (INIT == 0) lattice_load_state();   // run parameters from the state file's header (suncl.cpp:695)
     if (lattice_nd != 4) throw model_error("ND must be 4");
     if (precision != model_precision_double) throw model_error("only double precision is implemented");
     if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
@@ -315,6 +316,7 @@ void model::sweep(void)
         for (int dir = 0; dir < 4; dir++) {
             for (auto& s : SubLat) check(qcd_update(s.ctx, parity, dir), "qcd_update");
             UpdateEdges(dir, parity);
+            PRNG_counter++;
         }
 }
 
@@ -333,6 +335,15 @@ void model::measure(int index)
             for (int i = 0; i < 4; i++) pl[i] += b[i];
         }
     }
+    for (int i = 0; i < 2; i++) plq_raw_[i][index] = plq[i];
+    for (int i = 0; i < 4; i++) pl_raw_[i][index] = pl[i];
+    derive_sample(index);
+}
+
+// the sample's table entries from its raw lattice sums
+void model::derive_sample(int index)
+{
+    const double plq[2] = {plq_raw_[0][index], plq_raw_[1][index]};
     const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
     const double n3 = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2];
     const double g = lattice_group;
@@ -343,10 +354,330 @@ void model::measure(int index)
         act_[i][index] = BETA * (1 - p3[i] / g);
     }
     // SU(N)/suncl/su3cpu.cpp:1427-1430
-    pl_[0][index] = pl[0] / (n3 * g);
-    pl_[1][index] = pl[1] / (n3 * g);
-    pl_[2][index] = pl[2] / (n3 * g * g);
-    pl_[3][index] = pl[3] / (n3 * g * g * g * g);
+    pl_[0][index] = pl_raw_[0][index] / (n3 * g);
+    pl_[1][index] = pl_raw_[1][index] / (n3 * g);
+    pl_[2][index] = pl_raw_[2][index] / (n3 * g * g);
+    pl_[3][index] = pl_raw_[3][index] / (n3 * g * g * g * g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lattice state files (SU(N)/suncl/suncl.cpp:1857-2079).  Layout of the reference's .qcg:
+//   64-dword header | lattice_measurement (double2 x size_F) | lattice_energies (double2 x
+//   energies_size: raw S sums per sample) | lattice_energies_plq (same, raw plaquette sums) |
+//   [lattice_polyakov_loop (double2 x polyakov_loop_size: raw Re, Im sums)] | lattice_table
+//   (double4 rows, reference device layout).
+// After that this engine appends what the reference does not need (it replays its generator):
+//   "QCDRLX1\0" | u64 streams | u64 draws | ctl | slot 0 | slot 1 of the per-thread streams in
+//   GLOBAL stream order, so a file written by a run cut into parts loads into any other cut.
+
+static const unsigned int BIN_HEADER_SIZE = 64;     // suncl.cpp:60
+static const unsigned int SIZE_ALIGN = 256;         // buffer_size_align step (clinterface.cpp:1580-1590): workgroup size
+static unsigned int size_align(unsigned int n) { return (1 + (n - 1) / SIZE_ALIGN) * SIZE_ALIGN; }
+static unsigned int convert_str_uint(const char* str, unsigned int offset)   // suncl.cpp:709-716
+{
+    unsigned int result = 0, pointer = offset;
+    for (unsigned int i = 0; i < 4; i++)
+        if (pointer < strlen(str)) result += ((unsigned int)(unsigned char)str[pointer++] << (i * 8));
+    return result;
+}
+static void split_double(double x, unsigned int& low, unsigned int& high)
+{
+    unsigned long long u;
+    memcpy(&u, &x, sizeof(u));
+    low = (unsigned int)(u & 0xFFFFFFFFu);
+    high = (unsigned int)(u >> 32);
+}
+static double join_double(unsigned int low, unsigned int high)
+{
+    const unsigned long long u = ((unsigned long long)high << 32) | low;
+    double x;
+    memcpy(&x, &u, sizeof(x));
+    return x;
+}
+
+unsigned int model::energies_size() const { return size_align((unsigned int)ITER); }
+unsigned int model::table_row_size() const
+{
+    return size_align((unsigned int)(lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3]));
+}
+
+std::vector<unsigned int> model::lattice_make_bin_header(void) const   // suncl.cpp:1939-1988
+{
+    std::vector<unsigned int> r(BIN_HEADER_SIZE, 0u);
+    const char* bin_prefix = "QCDGPU";
+    int k = 0;
+    for (int i = 0; i < (int)ceil((double)strlen(bin_prefix) / 4); i++) r[k++] = convert_str_uint(bin_prefix, i * 4);
+    k = 2;
+    for (int i = 0; i < (int)ceil((double)version.size() / 4); i++) r[k++] = convert_str_uint(version.c_str(), i * 4);
+    k = 4;
+    r[k++] = (unsigned int)INIT;
+    r[k++] = ints == model_start_hot ? 0u : (ints == model_start_cold ? 1u : 2u);
+    r[k++] = PRNG0->PRNG_randseries;
+    r[k++] = 2u + (unsigned int)PRNG0->PRNG_generator;   // RANLUX0..4 = 2..6 (random.cpp:110-120)
+    static const unsigned int nskip[5] = {24, 48, 97, 223, 389};
+    r[k++] = nskip[PRNG0->lux_level()];
+    r[k++] = PRNG_counter;
+    r[k++] = (unsigned int)NAV;
+    r[k++] = (unsigned int)NAV_counter;
+    r[k++] = (unsigned int)NITER;
+    r[k++] = (unsigned int)ITER;
+    r[k++] = (unsigned int)ITER_counter;
+    r[k++] = (unsigned int)NHIT;
+    r[k++] = (unsigned int)wilson_R;
+    r[k++] = (unsigned int)wilson_T;
+    r[k++] = 2u;   // double precision
+    split_double(BETA, r[k], r[k + 1]); k += 2;
+    split_double(PHI, r[k], r[k + 1]); k += 2;
+    split_double(OMEGA, r[k], r[k + 1]); k += 2;
+    r[k++] = (unsigned int)PL_level;
+    r[k++] = 1u;   // Fmunu_index1, Fmunu_index2: not measured here, the reference's defaults
+    r[k++] = 2u;
+    r[k++] = 0u;   // get_Fmunu
+    r[k++] = get_actions_avr ? 1u : 0u;
+    r[k++] = get_plaquettes_avr ? 1u : 0u;
+    r[k++] = 0u;   // get_wilson_loop
+    r[k++] = 0u;   // lattice_measurement_size_F: the reduce scratch buffer is not part of this engine's state
+    r[k++] = energies_size();
+    r[k++] = energies_size();   // lattice_energies_size_F (no F_mu_nu)
+    r[k++] = energies_size();   // lattice_polyakov_loop_size
+    r[k++] = (unsigned int)lattice_group;
+    r[k++] = (unsigned int)lattice_nd;
+    for (int i = 0; i < lattice_nd; i++) r[k++] = (unsigned int)lattice_full_size[i];
+    for (int i = 0; i < lattice_nd; i++) r[k++] = (unsigned int)lattice_domain_size[i];
+    return r;
+}
+
+bool model::lattice_load_bin_header(const unsigned int* head)   // suncl.cpp:1990-2041
+{
+    const char* bin_prefix = "QCDGPU";
+    bool ok = true;
+    int k = 0;
+    for (int i = 0; i < (int)ceil((double)strlen(bin_prefix) / 4); i++) ok &= (head[k++] == convert_str_uint(bin_prefix, i * 4));
+    k = 2;
+    for (int i = 0; i < (int)ceil((double)version.size() / 4); i++) ok &= (head[k++] == convert_str_uint(version.c_str(), i * 4));
+    if (!ok) return false;
+    k = 5;
+    ints = head[k] == 0 ? model_start_hot : (head[k] == 2 ? model_start_gid : model_start_cold); k++;
+    PRNG0->PRNG_randseries = head[k++];
+    const unsigned int gen = head[k++];
+    if (gen < 2 || gen > 6) return false;
+    PRNG0->PRNG_generator = (PRNG::PRNG_generators)(gen - 2);
+    k++;   // RL_nskip follows from the generator
+    PRNG_counter = head[k++];
+    NAV = (int)head[k++];
+    NAV_counter = (int)head[k++];
+    NITER = (int)head[k++];
+    ITER = (int)head[k++];
+    ITER_counter = (int)head[k++];
+    NHIT = (int)head[k++];
+    wilson_R = (int)head[k++];
+    wilson_T = (int)head[k++];
+    if (head[k++] != 2u) return false;   // only double-precision states
+    BETA = join_double(head[k], head[k + 1]); k += 2;
+    PHI = join_double(head[k], head[k + 1]); k += 2;
+    OMEGA = join_double(head[k], head[k + 1]); k += 2;
+    PL_level = (int)head[k++];
+    k += 2;   // Fmunu indices
+    if (head[k++] != 0u) return false;   // F_mu_nu sections are not written or read by this engine
+    get_actions_avr = head[k++] != 0;
+    get_plaquettes_avr = head[k++] != 0;
+    if (head[k++] != 0u) return false;   // nor the Wilson loop section
+    state_sizes_[0] = head[k++];
+    state_sizes_[1] = head[k++];
+    state_sizes_[2] = head[k++];
+    state_sizes_[3] = head[k++];
+    lattice_group = (int)head[k++];
+    lattice_nd = (int)head[k++];
+    if (lattice_nd != 4) return false;
+    for (int i = 0; i < lattice_nd; i++) lattice_full_size[i] = (int)head[k++];
+    for (int i = 0; i < lattice_nd; i++) lattice_domain_size[i] = (int)head[k++];
+    return true;
+}
+
+void model::lattice_save_state(void)
+{
+    time_t now;
+    char* timesave = current_datetime(&now);
+    char name[64] = "";
+    snprintf(name, sizeof(name), "%.2s-%.3s-%.2s-%.2s-%.2s-%.2s.qcg", timesave + 22, timesave + 4, timesave + 8,
+             timesave + 11, timesave + 14, timesave + 17);
+    free(timesave);
+    state_file = path + fprefix + name;
+    FILE* stream = fopen(state_file.c_str(), "wb");
+    if (!stream) throw model_error("cannot write " + state_file);
+    const std::vector<unsigned int> head = lattice_make_bin_header();
+    fwrite(head.data(), sizeof(unsigned int), BIN_HEADER_SIZE, stream);
+
+    const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
+    const unsigned int es = energies_size();
+    std::vector<double> sec(2 * (size_t)es);
+    auto write_pairs = [&](const std::vector<double>& a, const std::vector<double>& b, double factor) {
+        std::fill(sec.begin(), sec.end(), 0.0);
+        for (int i = 0; i < ITER_counter && i < ITER; i++) {
+            sec[2 * i] = a[i] * factor;
+            sec[2 * i + 1] = b[i] * factor;
+        }
+        fwrite(sec.data(), 2 * sizeof(double), es, stream);
+    };
+    write_pairs(act_[0], act_[1], 3.0 * v);                               // lattice_energies: S x its denominator (suncl.cpp:1340-1348)
+    if (get_plaquettes_avr) write_pairs(plq_raw_[0], plq_raw_[1], 1.0);   // lattice_energies_plq: lattice sums
+    if (PL_level > 0) write_pairs(pl_raw_[0], pl_raw_[1], 1.0);           // lattice_polyakov_loop: Re, Im sums
+
+    // link table: rows of the whole lattice, each part's sites at their global position
+    const int rows = (lattice_group == 3) ? 12 : 4;
+    const unsigned int rs = table_row_size();
+    const size_t gslice = (size_t)lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
+    std::vector<double> table((size_t)rows * rs * 4, 0.0);
+    size_t x0 = 0;
+    for (auto& s : SubLat) {
+        const size_t nloc = (size_t)s.Nx * gslice;
+        std::vector<double> part((size_t)rows * nloc * 4);
+        check(qcd_download(s.ctx, part.data(), part.size() * sizeof(double), (int)nloc), "qcd_download");
+        for (int r = 0; r < rows; r++)
+            memcpy(&table[((size_t)r * rs + x0 * gslice) * 4], &part[(size_t)r * nloc * 4], nloc * 4 * sizeof(double));
+        x0 += (size_t)s.Nx;
+    }
+    fwrite(table.data(), 4 * sizeof(double), (size_t)rows * rs, stream);
+
+    // per-thread generator state in global stream order
+    const size_t NS = (size_t)lattice_full_size[0] * gslice / 2;
+    std::vector<unsigned int> ctl(NS), slots(2 * 25 * NS);
+    unsigned long long draws = 0;
+    size_t first = 0;
+    for (auto& s : SubLat) {
+        const size_t ns = (size_t)s.Nx * gslice / 2;
+        std::vector<unsigned char> st(qcd_rng_state_bytes(s.ctx));
+        check(qcd_rng_state_download(s.ctx, st.data(), st.size()), "qcd_rng_state_download");
+        unsigned long long d;
+        memcpy(&d, st.data(), sizeof(d));
+        draws += d;
+        const unsigned int* w = (const unsigned int*)(st.data() + sizeof(d));
+        memcpy(&ctl[first], w, ns * sizeof(unsigned int));
+        w += ns;
+        for (int slot = 0; slot < 2; slot++)
+            for (int k = 0; k < 25; k++, w += ns)
+                memcpy(&slots[((size_t)slot * 25 + k) * NS + first], w, ns * sizeof(unsigned int));
+        first += ns;
+    }
+    const char magic[8] = {'Q', 'C', 'D', 'R', 'L', 'X', '1', 0};
+    const unsigned long long ns64 = NS;
+    fwrite(magic, 1, 8, stream);
+    fwrite(&ns64, sizeof(ns64), 1, stream);
+    fwrite(&draws, sizeof(draws), 1, stream);
+    fwrite(ctl.data(), sizeof(unsigned int), ctl.size(), stream);
+    fwrite(slots.data(), sizeof(unsigned int), slots.size(), stream);
+    // the reference's Polyakov section holds Re and Im only; |P|^2 and |P|^4 sums follow here
+    const char magic2[8] = {'Q', 'C', 'D', 'P', 'L', '2', '4', 0};
+    const unsigned long long n64 = (unsigned long long)ITER;
+    fwrite(magic2, 1, 8, stream);
+    fwrite(&n64, sizeof(n64), 1, stream);
+    fwrite(pl_raw_[2].data(), sizeof(double), (size_t)ITER, stream);
+    fwrite(pl_raw_[3].data(), sizeof(double), (size_t)ITER, stream);
+    if (fclose(stream)) printf("The file was not closed!\n");
+    time(&last_save_);
+}
+
+// Two calls, as in the reference: the first (from lattice_init, before the contexts exist) reads
+// the header and sets the run parameters; the second (from lattice_simulate) reads the samples,
+// the configuration and the generator state into the contexts.
+void model::lattice_load_state(void)
+{
+    const std::string file = path + fstate;
+    FILE* stream = fopen(file.c_str(), "rb");
+    if (!stream) throw model_error("cannot read state file " + file);
+    std::vector<unsigned int> head(BIN_HEADER_SIZE);
+    bool ok = fread(head.data(), sizeof(unsigned int), BIN_HEADER_SIZE, stream) == BIN_HEADER_SIZE;
+    if (LOAD_state == 0) {
+        ok = ok && lattice_load_bin_header(head.data());
+        fclose(stream);
+        if (!ok) throw model_error("[ERROR in header!!!] " + file);
+        LOAD_state++;
+        return;
+    }
+    const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
+    const double g = lattice_group;
+    std::vector<double> sec;
+    auto read_pairs = [&](unsigned int count, std::vector<double>* a, std::vector<double>* b) {
+        sec.assign(2 * (size_t)count, 0.0);
+        ok = ok && fread(sec.data(), 2 * sizeof(double), count, stream) == count;
+        for (int i = 0; a && i < ITER_counter && i < ITER && (unsigned int)i < count; i++) {
+            (*a)[i] = sec[2 * i];
+            (*b)[i] = sec[2 * i + 1];
+        }
+    };
+    std::vector<double> s_raw[2] = {std::vector<double>(ITER, 0.0), std::vector<double>(ITER, 0.0)};
+    read_pairs(state_sizes_[0], nullptr, nullptr);                                      // lattice_measurement
+    read_pairs(state_sizes_[1], &s_raw[0], &s_raw[1]);                                  // lattice_energies
+    if (get_plaquettes_avr) read_pairs(state_sizes_[2], &plq_raw_[0], &plq_raw_[1]);    // lattice_energies_plq
+    else
+        for (int i = 0; i < ITER_counter && i < ITER; i++)   // plaquette sums back from S = beta (1 - Plq / N)
+            for (int c = 0; c < 2; c++) plq_raw_[c][i] = 3.0 * v * g * (1.0 - s_raw[c][i] / (3.0 * v) / BETA);
+    if (PL_level > 0) read_pairs(state_sizes_[3], &pl_raw_[0], &pl_raw_[1]);            // lattice_polyakov_loop
+    const int rows = (lattice_group == 3) ? 12 : 4;
+    const unsigned int rs = table_row_size();
+    const size_t gslice = (size_t)lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
+    std::vector<double> table((size_t)rows * rs * 4);
+    ok = ok && fread(table.data(), 4 * sizeof(double), (size_t)rows * rs, stream) == (size_t)rows * rs;
+    if (!ok) {
+        fclose(stream);
+        throw model_error("state file is truncated: " + file);
+    }
+    size_t x0 = 0;
+    for (auto& s : SubLat) {
+        const size_t nloc = (size_t)s.Nx * gslice;
+        std::vector<double> part((size_t)rows * nloc * 4);
+        for (int r = 0; r < rows; r++)
+            memcpy(&part[(size_t)r * nloc * 4], &table[((size_t)r * rs + x0 * gslice) * 4], nloc * 4 * sizeof(double));
+        check(qcd_init_lattice(s.ctx), "qcd_init_lattice");   // tables of the start mode (gid), stream seeds
+        check(qcd_upload(s.ctx, part.data(), part.size() * sizeof(double), (int)nloc), "qcd_upload");
+        x0 += (size_t)s.Nx;
+    }
+    // generator state (absent in files the reference wrote: the streams then start from their seeds)
+    char magic[8];
+    unsigned long long ns64 = 0, draws = 0;
+    const size_t NS = (size_t)lattice_full_size[0] * gslice / 2;
+    if (fread(magic, 1, 8, stream) == 8 && !memcmp(magic, "QCDRLX1", 8) && fread(&ns64, sizeof(ns64), 1, stream) == 1 &&
+        fread(&draws, sizeof(draws), 1, stream) == 1 && ns64 == NS) {
+        std::vector<unsigned int> ctl(NS), slots(2 * 25 * NS);
+        if (fread(ctl.data(), sizeof(unsigned int), NS, stream) != NS ||
+            fread(slots.data(), sizeof(unsigned int), slots.size(), stream) != slots.size()) {
+            fclose(stream);
+            throw model_error("generator state is truncated: " + file);
+        }
+        size_t first = 0;
+        bool first_part = true;
+        for (auto& s : SubLat) {
+            const size_t ns = (size_t)s.Nx * gslice / 2;
+            std::vector<unsigned char> st(qcd_rng_state_bytes(s.ctx));
+            const unsigned long long d = first_part ? draws : 0ull;   // the total is kept on the first part
+            memcpy(st.data(), &d, sizeof(d));
+            unsigned int* w = (unsigned int*)(st.data() + sizeof(d));
+            memcpy(w, &ctl[first], ns * sizeof(unsigned int));
+            w += ns;
+            for (int slot = 0; slot < 2; slot++)
+                for (int k = 0; k < 25; k++, w += ns)
+                    memcpy(w, &slots[((size_t)slot * 25 + k) * NS + first], ns * sizeof(unsigned int));
+            check(qcd_rng_state_upload(s.ctx, st.data(), st.size()), "qcd_rng_state_upload");
+            first += ns;
+            first_part = false;
+        }
+    } else {
+        printf("state file carries no generator state: streams start from their seeds\n");
+    }
+    char magic2[8];
+    unsigned long long n64 = 0;
+    if (fread(magic2, 1, 8, stream) == 8 && !memcmp(magic2, "QCDPL24", 8) && fread(&n64, sizeof(n64), 1, stream) == 1 &&
+        n64 == (unsigned long long)ITER) {
+        if (fread(pl_raw_[2].data(), sizeof(double), (size_t)ITER, stream) != (size_t)ITER ||
+            fread(pl_raw_[3].data(), sizeof(double), (size_t)ITER, stream) != (size_t)ITER)
+            printf("state file: |P|^2, |P|^4 sums are truncated\n");
+    }
+    fclose(stream);
+    for (int i = 0; i < ITER_counter && i < ITER; i++) derive_sample(i);
+    // halo slices of the parts
+    for (int dir = 0; dir < 4; dir++)
+        for (int parity = 0; parity < 2; parity++) UpdateEdges(dir, parity);
+    LOAD_state++;
 }
 
 // lattice_simulate (SU(N)/suncl/suncl.cpp:5212-5505): sample 0 on the initial configuration,
@@ -360,29 +691,52 @@ void model::lattice_simulate(void)
         act_[i].assign(ITER, 0.0);
     }
     for (int i = 0; i < 4; i++) pl_[i].assign(ITER, 0.0);
+    for (int i = 0; i < 2; i++) plq_raw_[i].assign(ITER, 0.0);
+    for (int i = 0; i < 4; i++) pl_raw_[i].assign(ITER, 0.0);
 
     free(timestart);
     timestart = current_datetime(&ltimestart);
-    for (auto& s : SubLat) check(qcd_init_lattice(s.ctx), "qcd_init_lattice");
-    // hot start: a part's halo slices hold its neighbours' random links only after an exchange
-    if (ints == model_start_hot)
-        for (int dir = 0; dir < 4; dir++)
-            for (int parity = 0; parity < 2; parity++) UpdateEdges(dir, parity);
-    int ITER_counter = 0;
-    measure(ITER_counter++);
-    for (int i = 0; i < NAV; i++) {
+    time(&last_save_);
+    if (INIT != 0) {
+        for (auto& s : SubLat) check(qcd_init_lattice(s.ctx), "qcd_init_lattice");
+        // hot start: a part's halo slices hold its neighbours' random links only after an exchange
+        if (ints == model_start_hot)
+            for (int dir = 0; dir < 4; dir++)
+                for (int parity = 0; parity < 2; parity++) UpdateEdges(dir, parity);
+        NAV_counter = 0;
+        ITER_counter = 0;
+        PRNG_counter = 0;
+        measure(ITER_counter++);
+        if (!turnoff_config_save) lattice_save_state();
+    } else {
+        lattice_load_state();   // samples so far, configuration, generator state (suncl.cpp:3956, 5349-5354)
+        printf("NAV_start=%i, ITER_start=%i\n", NAV_counter, ITER_counter);
+    }
+    // thermalisation (suncl.cpp:5356-5388)
+    for (int i = NAV_counter; i < NAV; i++) {
         sweep();
         if (i % 10 == 0) printf("\rGPU thermalization [%i]", i);
-    }
-    for (int i = 1; i < ITER; i++) {
-        for (int j = 0; j < NITER; j++) sweep();
-        if (!turnoff_gramschmidt && lattice_group == 2) {
-            // SU(2) links are products of unit quaternions and are not re-normalised by the
-            // sequential path (SU(N)/suncpp/su2/update_su2.cpp:121); nothing to do
+        NAV_counter++;
+        if (!turnoff_config_save && difftime(time(NULL), last_save_) > write_lattice_state_every_secs) {
+            lattice_save_state();
+            printf("\ncurrent configuration saved\n");
         }
+    }
+    // working cycles (suncl.cpp:5390-5495)
+    for (int i = ITER_counter; i < ITER; i++) {
+        for (int j = 0; j < NITER; j++) sweep();
         if (i % 10 == 0) printf("\rGPU working iteration [%u]", i);
         measure(ITER_counter++);
+        if (!turnoff_config_save && difftime(time(NULL), last_save_) > write_lattice_state_every_secs) {
+            lattice_save_state();
+            printf("\ncurrent configuration saved\n");
+        }
+        if (stop_at_sample > 0 && ITER_counter >= stop_at_sample && ITER_counter < ITER) {
+            stopped_early = true;
+            break;
+        }
     }
+    if (!turnoff_config_save) lattice_save_state();
     for (auto& s : SubLat) check(qcd_synchronize(s.ctx), "qcd_synchronize");
     free(timeend);
     timeend = current_datetime(&ltimeend);

@@ -121,6 +121,16 @@ public:
     bool get_plaquettes_avr = true;
     bool get_wilson_loop = false;  // accepted from init.dat, not measured by this engine
     bool profiling = false;        // GPU_debug.profiling
+    // lattice state files (SU(N)/suncl/suncl.h:80,154-175; defaults of main, QCDGPU.cpp:203,215)
+    bool turnoff_config_save = true;                 // do not write configurations
+    double write_lattice_state_every_secs = 15.0 * 60.0;
+    std::string fstate;                              // state file to continue from when INIT = 0
+    unsigned int PRNG_counter = 0;                   // update passes done (the reference: produce() calls)
+    int NAV_counter = 0;
+    int ITER_counter = 0;
+    std::string state_file;                          // name of the file lattice_save_state wrote last
+    int stop_at_sample = -1;                         // leave lattice_simulate once this many samples exist (an interrupted run)
+    bool stopped_early = false;
 
     PRNG* PRNG0;
 
@@ -149,6 +159,9 @@ public:
     const char* lattice_make_header(void);
     const char* lattice_make_header2(void);
     void print_time_detailed(void);
+    // <path><prefix>YY-Mon-DD-HH-MM-SS.qcg (SU(N)/suncl/suncl.cpp:1857-2079)
+    void lattice_save_state(void);
+    void lattice_load_state(void);
 
     // halo exchange after a pass over links of direction dir on the sites of one parity
     // (model::UpdateEdges, SU(N)/suncl/suncl.cpp:4005-4061)
@@ -156,10 +169,19 @@ public:
 
 private:
     std::vector<double> plq_[3], act_[3], pl_[4];
+    std::vector<double> plq_raw_[2], pl_raw_[4];   // per sample: the lattice sums the table entries derive from
+    void derive_sample(int index);
     std::string device_names_;
     void sweep(void);
     void measure(int index);
     void check(int rc, const char* what);
+    unsigned int LOAD_state = 0;
+    std::vector<unsigned int> lattice_make_bin_header(void) const;
+    bool lattice_load_bin_header(const unsigned int* head);
+    unsigned int energies_size() const;
+    unsigned int table_row_size() const;
+    time_t last_save_ = 0;
+    unsigned int state_sizes_[4] = {0, 0, 0, 0};   // section lengths read from a state file's header
 };
 
 }  // namespace model_HIP

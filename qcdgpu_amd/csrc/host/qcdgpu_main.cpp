@@ -2,7 +2,8 @@
 // hard-coded defaults, argv[1] = init.dat overriding them, then
 // lattice_init -> lattice_simulate -> lattice_analysis -> lattice_write_results -> lattice_print_measurements.
 //
-//   qcdgpu [init.dat] [--profile]
+//   qcdgpu [init.dat] [--profile] [--save-state [--save-every SECONDS]] [--stop-at SAMPLE]
+//   qcdgpu [init.dat] --load FILE.qcg   continue the run FILE.qcg (in OUTPUTPATH) was saved from
 //   qcdgpu --parse-only init.dat     print the run parameters as JSON, touch no device
 //   qcdgpu --stats v0 v1 v2 ...      mean and variance of a series (sample 0 excluded)
 #include <cstdio>
@@ -36,6 +37,13 @@ int main(int argc, char** argv)
         bool parse_only = false;
         for (int i = 1; i < argc; i++) {
             if (!strcmp(argv[i], "--profile")) model0->profiling = true;
+            else if (!strcmp(argv[i], "--save-state")) model0->turnoff_config_save = false;
+            else if (!strcmp(argv[i], "--save-every") && i + 1 < argc) model0->write_lattice_state_every_secs = atof(argv[++i]);
+            else if (!strcmp(argv[i], "--stop-at") && i + 1 < argc) model0->stop_at_sample = atoi(argv[++i]);
+            else if (!strcmp(argv[i], "--load") && i + 1 < argc) {
+                model0->INIT = 0;   // continue (SU(N)/QCDGPU.cpp:180, 234-235)
+                model0->fstate = argv[++i];
+            }
             else if (!strcmp(argv[i], "--parse-only")) parse_only = true;
             else if (!strcmp(argv[i], "--stats")) {
                 model_HIP::data_analysis d;
@@ -73,6 +81,12 @@ int main(int argc, char** argv)
         model0->lattice_init();
         printf("%s\n", model0->header.c_str());
         model0->lattice_simulate();
+        if (!model0->state_file.empty()) printf("state file: %s\n", model0->state_file.c_str());
+        if (model0->stopped_early) {
+            printf("stopped after sample %d as asked; continue with --load\n", model0->ITER_counter - 1);
+            delete model0;
+            return 0;
+        }
         model0->lattice_analysis();
         model0->lattice_write_results();
         model0->lattice_print_measurements();

@@ -15,16 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 QCDGPU = os.path.join(ROOT, "qcdgpu_amd", "bin", "qcdgpu")
 
 
-def _run(tmp_path, keys, extra=""):
+def _run(tmp_path, keys, extra="", args=()):
     tmp_path.mkdir(exist_ok=True)
     with open(tmp_path / "init.dat", "w") as f:
         for k, v in keys.items():
             f.write("\t%s = %s\n" % (k, v))
         f.write(extra)
         f.write("\tOUTPUTPATH = %s/\n" % tmp_path)
-    r = subprocess.run([QCDGPU, str(tmp_path / "init.dat")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([QCDGPU, str(tmp_path / "init.dat")] + list(args), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr + r.stdout[-2000:]
     m = re.search(r"result file: (\S+)", r.stdout)
+    if m is None:
+        return None, None, None, r.stdout
     rows, fields, in_table = [], None, False
     text = open(m.group(1)).read()
     for line in text.splitlines():
@@ -89,6 +91,59 @@ def test_cli_hot_start_single_and_biglattice(tmp_path):
     lat.sweep(2)
     assert np.max(np.abs(single[1, :3] - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-11
     lat.close()
+
+
+def test_cli_state_file_resume_is_exact(tmp_path):
+    """lattice_save_state / lattice_load_state: a run stopped after sample 2 and continued from
+    its .qcg file gives the same table, digit for digit, as the uninterrupted run -- also when
+    the continuation cuts the lattice into parts.  The file starts with the reference's header."""
+    import shutil
+    import struct
+    keys = dict(GROUP=3, ND=4, L1=8, L2=4, L3=6, L4=4, BETA=5.7, NHIT=4, INTS=1, PRNG="RANLUX2",
+                RANDSERIES=77, NAV=2, ITER=6, NITER=2)
+    _, _, full, _ = _run(tmp_path / "a", keys)
+    _, _, none, out = _run(tmp_path / "b", keys, args=["--save-state", "--save-every", "1e9", "--stop-at", "3"])
+    assert none is None and "stopped after sample 2" in out
+    qcg = re.findall(r"state file: (\S+)", out)[-1]
+    raw = open(qcg, "rb").read()
+    head = struct.unpack("<64I", raw[:256])
+    assert raw[:6] == b"QCDGPU" and raw[8:11] == b"1.5"
+    assert head[5] == 1 and head[6] == 77 and head[7] == 4 and head[8] == 97      # cold, seed, RANLUX2, nskip
+    assert head[9] == 8 * (2 + 2 * 2) and head[10] == 2 and head[11] == 2         # passes, NAV, NAV_counter
+    assert head[12] == 2 and head[13] == 6 and head[14] == 3 and head[15] == 4    # NITER, ITER, ITER_counter, NHIT
+    assert struct.unpack("<d", raw[19 * 4:21 * 4])[0] == 5.7
+    assert head[36:46] == (3, 4, 8, 4, 6, 4, 8, 4, 6, 4)
+    # the link table sits where the reference's reader expects it: header, three sample sections of
+    # align(ITER) double2, then 12 rows of align(sites) double4 in the reference device layout
+    sites, rs = 8 * 4 * 6 * 4, 768
+    off = 256 + 3 * 256 * 16
+    table = np.frombuffer(raw[off:off + 12 * rs * 32], dtype=np.float64).reshape(12, rs, 4)
+    u = table[0:4, :sites, :3] + 1j * table[4:8, :sites, :3]
+    assert np.max(np.abs(np.sum(np.abs(u) ** 2, axis=2) - 1)) < 1e-14
+    assert raw[off + 12 * rs * 32:off + 12 * rs * 32 + 7] == b"QCDRLX1"
+    for name, extra in (("c", ""), ("d", "\tN1 = {2, 6}\n\tDEVICE = {0, 0}\n")):
+        (tmp_path / name).mkdir()
+        shutil.copy(qcg, tmp_path / name / "state.qcg")
+        _, _, resumed, out2 = _run(tmp_path / name, keys, extra, args=["--load", "state.qcg"])
+        assert "NAV_start=2, ITER_start=3" in out2
+        assert np.array_equal(resumed, full), name
+
+
+def test_rng_state_roundtrip_through_the_c_abi():
+    import qcdgpu_amd as q
+    kw = dict(group=2, L=(4, 4, 4, 4), beta=2.2, nhit=3, rand_series=5)
+    with q.Context(**kw) as a, q.Context(**kw) as b:
+        a.init_lattice(); b.init_lattice()
+        a.sweep(2)
+        st, links = a.rng_state(), a.download()
+        a.sweep(1)
+        b.upload(links)
+        b.set_rng_state(st)
+        b.sweep(1)
+        assert np.array_equal(a.download(), b.download())
+        assert a.rng_draws() == b.rng_draws()
+        with pytest.raises(q.QcdError):
+            b.set_rng_state(st[:-4])
 
 
 def test_biglattice_python_driver_on_one_gpu():
