@@ -738,17 +738,17 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
 #endif
         mat<GROUP> A, Ul;
         if constexpr (GROUP == 3) {
-            // the stream's control word is requested first, its state and the link itself before
-            // the last staple term is worked out: both round trips are over when the staple is
+            // the stream's control word is requested first, so that its state can be requested
+            // without a second round trip as soon as the staple's registers are free (requesting
+            // state and link under the last staple term costs 40 registers and gains nothing)
             if (!GID) rs.attach(rv, t, rbuf + threadIdx.x);
             StaplePipe sp;
             staple_pipe_head<DIR>(sp, U, g, hb, nbr, parity);
             raw_link own;
             RlxRegs r;
-            staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, [&]() {
-                own = issue_link(r_own, g, hb);
-                if (!GID) rs.fetch(r);
-            });
+            staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, NoHook());
+            own = issue_link(r_own, g, hb);
+            if (!GID) rs.fetch(r);
             A = sp.stap;
             QCD_STAMP(1);
             pin(own);
