@@ -163,6 +163,12 @@ int qcd_rng_draws(qcd_ctx *ctx, unsigned long long *draws);
 int qcd_prng_check(int device, unsigned rand_series, int lux_level, int streams, int samples,
                    unsigned *errors);
 
+/* self-check of the engine's own fp64 reciprocal, square root and logarithm (hardware seeds +
+ * table; no counterpart in the reference, which calls the OpenCL built-ins): worst error, in
+ * units of the last place, of log(1-x), sqrt(x), 1/(x+1e-3), 1/sqrt(x+1e-3) over n arguments
+ * x = k * 2^-24 in (0, 1), against the host libm in long double */
+int qcd_math_check(int device, int n, double max_ulp[4]);
+
 #ifdef __cplusplus
 }
 #endif

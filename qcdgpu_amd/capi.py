@@ -42,7 +42,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
-           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload"]
+           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check"]
 
 
 def _load():
@@ -90,6 +90,7 @@ def _load():
     # host-only helpers (no device needed)
     lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
     lib.qcd_prng_check.argtypes = [I, C.c_uint, I, I, I, C.POINTER(C.c_uint)]
+    lib.qcd_math_check.argtypes = [I, I, C.POINTER(C.c_double)]
     lib.qcd_rng_state_bytes.restype = C.c_size_t
     lib.qcd_rng_state_bytes.argtypes = [P]
     lib.qcd_rng_state_download.argtypes = [P, C.c_void_p, C.c_size_t]
@@ -242,6 +243,13 @@ def prng_check(device=0, rand_series=54, lux_level=3, streams=256, samples=240):
     bad = C.c_uint()
     _check(lib.qcd_prng_check(device, rand_series, lux_level, streams, samples, C.byref(bad)))
     return bad.value
+
+
+def math_check(device=0, n=1 << 20):
+    """Worst error (ulp) of the engine's own log(1-x), sqrt, 1/x, 1/sqrt against the host libm."""
+    out = (C.c_double * 4)()
+    _check(lib.qcd_math_check(device, n, out))
+    return np.array(out[:])
 
 
 def host_ranlux_stream(rand_series, stream, lux_level, n):

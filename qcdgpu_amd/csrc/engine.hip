@@ -138,6 +138,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir)
     a.parity = parity;
     a.nhit = c->p.nhit;
     a.beta_eff = beta_eff;
+    a.beta_inv = 1.0 / beta_eff;
     a.rv = c->rv;
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
@@ -954,6 +955,60 @@ int qcd_prng_check(int device, unsigned rand_series, int lux_level, int streams,
         }
     }
     *errors = bad;
+    return QCD_OK;
+}
+
+// Self-check of the heat-bath's own fp64 reciprocal / square root / logarithm (fastmath.h)
+// against the host libm: n arguments x_i in (0, 1) (as floats k * 2^-24, the form the heat-bath
+// feeds them), worst error in units of the last place of: log(1 - x), sqrt(x), 1/(x + 1e-3),
+// 1/sqrt(x + 1e-3).
+int qcd_math_check(int device, int n, double max_ulp[4])
+{
+    if (!max_ulp || n < 1) return fail(QCD_ERR_INVALID, "bad arguments");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(QCD_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<double> in((size_t)n), out((size_t)4 * n);
+    unsigned long long lcg = 88172645463325252ull;
+    for (int i = 0; i < n; i++) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        unsigned k = (unsigned)(lcg >> 40);                 // 24 bits
+        if (i % 7 == 0) k >>= (i / 7) % 24;                 // also small arguments (1 - x close to 1)
+        if (i % 11 == 0) k = 0xFFFFFFu - (k >> ((i / 11) % 24));   // and arguments close to 1
+        if (k == 0) k = 1;
+        in[(size_t)i] = (double)((float)k * 5.9604644775390625e-8f);
+    }
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, in.size() * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, out.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_in, in.data(), in.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_math_check<MEAS_BLOCK>), dim3(cdiv((long)n, MEAS_BLOCK)), dim3(MEAS_BLOCK), 0, 0, d_in, n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(QCD_ERR_HIP, "math check: %s", hipGetErrorString(e));
+    auto ulps = [](double got, long double want) {
+        if (want == 0.0L) return got == 0.0 ? 0.0 : 1e30;
+        const double u = std::ldexp(1.0, std::ilogb((double)want) - 52);
+        return (double)(fabsl((long double)got - want) / u);
+    };
+    for (int k = 0; k < 4; k++) max_ulp[k] = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double x = in[(size_t)i];
+        const long double w[4] = {logl(1.0L - (long double)(float)x), sqrtl((long double)x), 1.0L / ((long double)x + 1e-3L),
+                                  1.0L / sqrtl((long double)(x + 1e-3))};
+        const long double arg2 = (long double)(x + 1e-3);   // the kernel adds in fp64
+        const long double w2 = 1.0L / arg2;
+        for (int k = 0; k < 4; k++) {
+            const long double want = (k == 2) ? w2 : w[k];
+            const double u = ulps(out[(size_t)k * n + i], want);
+            if (u > max_ulp[k]) max_ulp[k] = u;
+        }
+    }
     return QCD_OK;
 }
 

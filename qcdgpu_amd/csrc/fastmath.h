@@ -1,0 +1,109 @@
+// fastmath.h -- fp64 reciprocal, square root and logarithm for the heat-bath, built from the
+// hardware seeds (v_rcp_f64, v_rsq_f64) and a 128-entry table instead of the device libm.
+//
+// Why: the heat-bath part of the update pass is issue-bound (every fp64 instruction on a wave's
+// critical path costs its full 4-cycle slot), and the libm routines spend most of their
+// instructions on cases that cannot occur here (denormals, infinities, arguments far from 1,
+// double-double tails for the last half ulp).  Accuracy of these versions: <= 1-2 ulp on the
+// argument ranges the heat-bath produces (checked against libm in tests); the CPU checker uses
+// glibc, which the device libm does not match bit for bit either.
+//
+// Two interchangeable policies: MathLib (device libm, used off the hot path) and MathFast.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace qcd {
+
+struct MathLib {
+    __device__ __forceinline__ double rcp(double x) const { return 1.0 / x; }
+    __device__ __forceinline__ double sqrt_of(double x) const { return sqrt(x); }
+    // s = sqrt(x), is = 1/s
+    __device__ __forceinline__ void sqrt_rcp(double x, double& s, double& is) const
+    {
+        s = sqrt(x);
+        is = 1.0 / s;
+    }
+    __device__ __forceinline__ double log_of(double x) const { return log(x); }
+    __device__ __forceinline__ float rcp32(double x) const { return (float)(1.0 / x); }
+};
+
+constexpr int LOG_TABLE_ENTRIES = 128;
+
+struct MathFast {
+    const double2* tab;   // LDS: (inv_j, -log(inv_j)), j = leading 7 fraction bits of the mantissa
+
+    // one thread per entry fills the table (call with every thread of the block, then barrier)
+    template <int BLOCK>
+    __device__ static void fill(double2* t)
+    {
+        for (int j = threadIdx.x; j < LOG_TABLE_ENTRIES; j += BLOCK) {
+            // centre of the j-th mantissa interval of f in [0.5, 1); the last interval is
+            // anchored at 1 so that arguments just below 1 lose nothing to cancellation
+            const double fc = (j == LOG_TABLE_ENTRIES - 1) ? 1.0 : 0.5 * (1.0 + (j + 0.5) / LOG_TABLE_ENTRIES);
+            const double inv = 1.0 / fc;
+            t[j] = make_double2(inv, -log(inv));
+        }
+    }
+
+    // normal, positive x well inside the exponent range (here: norms of 2x2 blocks, 1e-3 .. 1e2)
+    __device__ __forceinline__ double rcp(double x) const
+    {
+        double y = __builtin_amdgcn_rcp(x);
+        double e = __builtin_fma(-x, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-x, y, 1.0);
+        return __builtin_fma(y, e, y);
+    }
+    __device__ __forceinline__ float rcp32(double x) const { return __builtin_amdgcn_rcpf((float)x); }
+
+    // x >= 0, not denormal; Goldschmidt iteration from the hardware reciprocal square root
+    __device__ __forceinline__ void sqrt_rcp(double x, double& s, double& is) const
+    {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y;            // ~ sqrt(x)
+        double h = 0.5 * y;          // ~ 1 / (2 sqrt(x))
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        r = __builtin_fma(-h, g, 0.5);
+        h = __builtin_fma(h, r, h);
+        const double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        s = g;
+        is = h + h;
+    }
+    __device__ __forceinline__ double sqrt_of(double x) const
+    {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y;
+        double h = 0.5 * y;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        const double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        return (x == 0.0) ? 0.0 : g;   // rsq(0) = inf
+    }
+
+    // 0 < x <= 1, normal: x = f 2^e, f in [0.5, 1); f = (1 + z) / inv_j with |z| <= 2^-7, so
+    // log x = e ln2 - log(inv_j) + log1p(z) holds exactly for the ROUNDED table value inv_j
+    __device__ __forceinline__ double log_of(double x) const
+    {
+        const double f = __builtin_amdgcn_frexp_mant(x);
+        const int e = __builtin_amdgcn_frexp_exp(x);
+        const int j = (__double2hiint(f) >> 13) & (LOG_TABLE_ENTRIES - 1);
+        const double2 t = tab[j];
+        const double z = __builtin_fma(f, t.x, -1.0);
+        double p = __builtin_fma(z, 1.0 / 7.0, -1.0 / 6.0);
+        p = __builtin_fma(p, z, 1.0 / 5.0);
+        p = __builtin_fma(p, z, -1.0 / 4.0);
+        p = __builtin_fma(p, z, 1.0 / 3.0);
+        p = __builtin_fma(p, z, -0.5);
+        p = p * z;
+        p = __builtin_fma(p, z, z);   // log1p(z)
+        return __builtin_fma((double)e, 0.693147180559945309417232121458, t.y) + p;
+    }
+};
+
+}  // namespace qcd

@@ -278,17 +278,20 @@ struct GidSource {
 // cospi/sincospi reduce the argument exactly and are half the instructions
 __device__ __forceinline__ double cos_2pi(float r) { return cospi(2.0 * (double)r); }
 
-template <bool GID, class Rng>
-__device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int nhit, Rng& rng, su2& out)
+// `m`: where reciprocal, square root and logarithm come from (fastmath.h).  beta_inv = 1 / beta.
+template <bool GID, class Rng, class Math>
+__device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, double beta_inv, int nhit, Rng& rng,
+                                             const Math& m, su2& out)
 {
     const double Mx = (stap.e[0][0].re + stap.e[1][1].re);
     const double My = (stap.e[0][0].im - stap.e[1][1].im);
     const double Mz = (stap.e[0][1].re - stap.e[1][0].re);
     const double Mw = (stap.e[0][1].im + stap.e[1][0].im);
 
-    const double det = sqrt(Mx * Mx + My * My + Mz * Mz + Mw * Mw);
+    double det, idet;
+    m.sqrt_rcp(Mx * Mx + My * My + Mz * Mz + Mw * Mw, det, idet);
     const double bdet = beta * det;
-    const double idet = 1.0 / det;
+    const double ibdet = beta_inv * idet;   // the reference divides by bdet; <= 1 ulp apart
 
     su2 aH;
     aH.e[0][0] = mk(Mx * idet, -My * idet);
@@ -303,10 +306,10 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int n
         // INTS = 2: the first trial is always accepted (update_su2.cpp:87-90)
         rng.draw4(rnd);
         const double cosrnd = cos_2pi(rnd[1]);
-        delta = cosrnd * cosrnd / bdet;
+        delta = cosrnd * cosrnd * ibdet;
         flag = true;
     } else {
-        const float ibdet32 = (float)(1.0 / bdet);
+        const float ibdet32 = m.rcp32(bdet);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;  // r0, r1, r2 of the accepted trial
         int i = 0;
         while ((i < nhit) && !flag) {
@@ -323,7 +326,7 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int n
             bool acc = t32 > margin;
             if (fabsf(t32) <= margin) {
                 const double cosrnd = cos_2pi(rnd[1]);
-                const double d = -(log(1.0 - rnd[0]) + cosrnd * cosrnd * log(1.0 - rnd[2])) / bdet;
+                const double d = -(m.log_of(1.0 - rnd[0]) + cosrnd * cosrnd * m.log_of(1.0 - rnd[2])) * ibdet;
                 acc = (r3sq <= (1.0 - 0.5 * d));
             }
             if (acc) {
@@ -336,15 +339,15 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int n
         }
         if (flag) {
             const double cosrnd = cos_2pi(a1);
-            delta = -(log(1.0 - a0) + cosrnd * cosrnd * log(1.0 - a2)) / bdet;
+            delta = -(m.log_of(1.0 - a0) + cosrnd * cosrnd * m.log_of(1.0 - a2)) * ibdet;
         }
     }
     if (flag) {
         rng.draw2(rnd);
         const double cosal = 1.0 - delta;
         const double costh = 2.0 * rnd[0] - 1.0;
-        const double sinth = sqrt(1.0 - costh * costh);
-        const double sinal = sqrt(1.0 - cosal * cosal);
+        const double sinth = m.sqrt_of(1.0 - costh * costh);
+        const double sinal = m.sqrt_of(1.0 - cosal * cosal);
         double sinphi, cosphi;
         sincospi(2.0 * (double)rnd[1], &sinphi, &cosphi);
         su2 c;
@@ -361,8 +364,9 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, int n
 // only the 2x2 block of U*A that the subgroup needs is formed, and only rows P and Q of U
 // change under the embedded SU(2) element (the other products of the reference are with exact
 // zeros and ones).
-template <int P, int Q, bool GID, class Rng>
-__device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, int nhit, Rng& rng)
+template <int P, int Q, bool GID, class Rng, class Math>
+__device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, double beta_inv, int nhit, Rng& rng,
+                                        const Math& m)
 {
     su2 blk;
     blk.e[0][0] = dot3(U.e[P][0], U.e[P][1], U.e[P][2], A.e[0][P], A.e[1][P], A.e[2][P]);
@@ -370,7 +374,7 @@ __device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, int n
     blk.e[1][0] = dot3(U.e[Q][0], U.e[Q][1], U.e[Q][2], A.e[0][P], A.e[1][P], A.e[2][P]);
     blk.e[1][1] = dot3(U.e[Q][0], U.e[Q][1], U.e[Q][2], A.e[0][Q], A.e[1][Q], A.e[2][Q]);
     su2 r;
-    if (heatbath_su2<GID>(blk, beta, nhit, rng, r)) {
+    if (heatbath_su2<GID>(blk, beta, beta_inv, nhit, rng, m, r)) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const cplx up = U.e[P][j], uq = U.e[Q][j];
@@ -380,26 +384,28 @@ __device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, int n
     }
 }
 
-template <bool GID, class Rng>
-__device__ __forceinline__ void update_link(su3& U, const su3& A, double beta, int nhit, Rng& rng)
+template <bool GID, class Rng, class Math>
+__device__ __forceinline__ void update_link(su3& U, const su3& A, double beta, double beta_inv, int nhit, Rng& rng,
+                                            const Math& m)
 {
 #ifdef QCD_ABL_HB  // diagnostic build: no heat-bath, keeps loads, staple products and the store
     add_to(U, A);
-    gram_schmidt(U);
+    gram_schmidt(U, m);
     return;
 #endif
-    cm_step<0, 1, GID>(U, A, beta, nhit, rng);
-    cm_step<0, 2, GID>(U, A, beta, nhit, rng);
-    cm_step<1, 2, GID>(U, A, beta, nhit, rng);
-    gram_schmidt(U);
+    cm_step<0, 1, GID>(U, A, beta, beta_inv, nhit, rng, m);
+    cm_step<0, 2, GID>(U, A, beta, beta_inv, nhit, rng, m);
+    cm_step<1, 2, GID>(U, A, beta, beta_inv, nhit, rng, m);
+    gram_schmidt(U, m);
 }
 // SU(2): the new link does not depend on the old one; unchanged when no trial is accepted
 // (update_su2.cpp:121-125 with final = 1, SU(N)/suncpp/Update/sun_update.h:94)
-template <bool GID, class Rng>
-__device__ __forceinline__ void update_link(su2& U, const su2& A, double beta, int nhit, Rng& rng)
+template <bool GID, class Rng, class Math>
+__device__ __forceinline__ void update_link(su2& U, const su2& A, double beta, double beta_inv, int nhit, Rng& rng,
+                                            const Math& m)
 {
     su2 r;
-    if (heatbath_su2<GID>(A, beta, nhit, rng, r)) U = r;
+    if (heatbath_su2<GID>(A, beta, beta_inv, nhit, rng, m, r)) U = r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,6 +685,7 @@ struct UpdArgs {
     int parity;
     int nhit;
     double beta_eff;
+    double beta_inv;       // 1 / beta_eff
     RlxView rv;
     const float* gidr;
     unsigned long long* draws;
@@ -693,6 +700,11 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs the signature only
     __shared__ float rbuf[GID ? 1 : 24 * RLX_WINDOW * BLOCK];
+    __shared__ double2 logtab[LOG_TABLE_ENTRIES];
+    MathFast::fill<BLOCK>(logtab);
+    __syncthreads();
+    MathFast fm;
+    fm.tab = logtab;
     unsigned long long used = 0;
     (void)args_by_value;
     typedef const UpdArgs __attribute__((address_space(4))) * ArgPtr;
@@ -770,9 +782,9 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             for (int k = 0; k < 4; k++) src.trial[k] = gidr[k * n + lg];
             src.accept[0] = gidr[4 * n + lg];
             src.accept[1] = gidr[5 * n + lg];
-            update_link<true>(Ul, A, beta_eff, nhit, src);
+            update_link<true>(Ul, A, beta_eff, ap->beta_inv, nhit, src, fm);
         } else {
-            update_link<false>(Ul, A, beta_eff, nhit, rs);
+            update_link<false>(Ul, A, beta_eff, ap->beta_inv, nhit, rs, fm);
             QCD_STAMP(3);
             const int n = rs.close();
             if (n < 0) {
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_redo(const UpdArgs a)
         mat<GROUP> Ul = load_link_buf(r_own, a.g, hb, (mat<GROUP>*)nullptr);
         RlxStream<BLOCK> slow;
         slow.open(a.rv, t, rbuf + threadIdx.x);
-        update_link<false>(Ul, A, a.beta_eff, a.nhit, slow);
+        update_link<false>(Ul, A, a.beta_eff, a.beta_inv, a.nhit, slow, MathLib());
         used += (unsigned long long)slow.close();
         store_link_buf(r_own, a.g, hb, Ul);
     }
@@ -1106,6 +1118,28 @@ __global__ __launch_bounds__(BLOCK) void k_rlx_dump(const unsigned* __restrict__
         rlx_batch(r, out + (size_t)24 * b * ns + i, ns);
         rlx_skip(r, q, rem);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// self-check of fastmath.h: in[i] -> out[0][i] = log(1 - (float)in[i]) (the heat-bath's argument
+// form), out[1][i] = sqrt(in[i]), out[2][i] = 1 / (in[i] + 1e-3), out[3][i] = 1/sqrt from sqrt_rcp
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_math_check(const double* __restrict__ in, const int n, double* __restrict__ out)
+{
+    __shared__ double2 logtab[LOG_TABLE_ENTRIES];
+    MathFast::fill<BLOCK>(logtab);
+    __syncthreads();
+    MathFast fm;
+    fm.tab = logtab;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    out[i] = fm.log_of(1.0 - (float)x);
+    out[n + i] = fm.sqrt_of(x);
+    out[2 * n + i] = fm.rcp(x + 1e-3);
+    double s, is;
+    fm.sqrt_rcp(x + 1e-3, s, is);
+    out[3 * n + i] = is;
 }
 
 // ---------------------------------------------------------------------------------------------

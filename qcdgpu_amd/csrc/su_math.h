@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "fastmath.h"
+
 namespace qcd {
 
 struct cplx {
@@ -142,15 +144,16 @@ __device__ __forceinline__ void reconstruct(su2& a)
     a.e[1][1] = mk(a.e[0][0].re, -a.e[0][0].im);
 }
 
-// Gram-Schmidt re-unitarisation (SU(N)/suncpp/su3/algebra_su3.cpp:185-217)
-__device__ __forceinline__ void gram_schmidt(su3& a)
+// Gram-Schmidt re-unitarisation (SU(N)/suncpp/su3/algebra_su3.cpp:185-217).  `m` supplies the
+// square root and reciprocal (device libm or the hardware-seeded versions of fastmath.h).
+template <class Math>
+__device__ __forceinline__ void gram_schmidt(su3& a, const Math& m)
 {
     cplx u1 = a.e[0][0], u2 = a.e[0][1], u3 = a.e[0][2];
     cplx v1 = a.e[1][0], v2 = a.e[1][1], v3 = a.e[1][2];
-    const double norm_u = sqrt(u1.re * u1.re + u2.re * u2.re + u3.re * u3.re + u1.im * u1.im +
-                               u2.im * u2.im + u3.im * u3.im);
-    // one reciprocal and six products instead of the reference's six quotients (<= 1 ulp apart)
-    const double iu = 1.0 / norm_u;
+    // one reciprocal norm and six products instead of the reference's six quotients (<= 1 ulp apart)
+    double norm_u, iu;
+    m.sqrt_rcp(u1.re * u1.re + u2.re * u2.re + u3.re * u3.re + u1.im * u1.im + u2.im * u2.im + u3.im * u3.im, norm_u, iu);
     u1 = mk(u1.re * iu, u1.im * iu);
     u2 = mk(u2.re * iu, u2.im * iu);
     u3 = mk(u3.re * iu, u3.im * iu);
@@ -158,9 +161,8 @@ __device__ __forceinline__ void gram_schmidt(su3& a)
     v1 = csub(v1, cmul(u1, sp));
     v2 = csub(v2, cmul(u2, sp));
     v3 = csub(v3, cmul(u3, sp));
-    const double norm_v = sqrt(v1.re * v1.re + v2.re * v2.re + v3.re * v3.re + v1.im * v1.im +
-                               v2.im * v2.im + v3.im * v3.im);
-    const double iv = 1.0 / norm_v;
+    double norm_v, iv;
+    m.sqrt_rcp(v1.re * v1.re + v2.re * v2.re + v3.re * v3.re + v1.im * v1.im + v2.im * v2.im + v3.im * v3.im, norm_v, iv);
     v1 = mk(v1.re * iv, v1.im * iv);
     v2 = mk(v2.re * iv, v2.im * iv);
     v3 = mk(v3.re * iv, v3.im * iv);
@@ -168,6 +170,7 @@ __device__ __forceinline__ void gram_schmidt(su3& a)
     a.e[1][0] = v1; a.e[1][1] = v2; a.e[1][2] = v3;
     reconstruct(a);
 }
+__device__ __forceinline__ void gram_schmidt(su3& a) { gram_schmidt(a, MathLib()); }
 // SU(2): normalise the first row, rebuild the second (kernel lattice_GramSchmidt,
 // SU(N)/suncl/suncl.cl:349-396 with lattice_su2_Normalize)
 __device__ __forceinline__ void gram_schmidt(su2& a)

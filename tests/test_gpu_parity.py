@@ -167,6 +167,14 @@ def test_device_generator_reproduces_cpu_generator(lux):
         assert np.array_equal(q.host_ranlux_stream(54, stream, lux, 100), want)
 
 
+def test_heatbath_math_is_accurate_to_the_last_places():
+    """The update kernel's own log / sqrt / reciprocal (hardware seed + refinement, table log)
+    against the host libm in long double, on the argument forms the heat-bath feeds them."""
+    import qcdgpu_amd as q
+    log_ulp, sqrt_ulp, rcp_ulp, rsqrt_ulp = q.math_check(device=0, n=1 << 20)
+    assert log_ulp <= 2.0 and sqrt_ulp <= 1.0 and rcp_ulp <= 1.5 and rsqrt_ulp <= 2.5, (log_ulp, sqrt_ulp, rcp_ulp, rsqrt_ulp)
+
+
 def test_config1_su3_16_plaquette_vs_cpu():
     """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)
