@@ -175,6 +175,23 @@ def test_heatbath_math_is_accurate_to_the_last_places():
     assert log_ulp <= 2.0 and sqrt_ulp <= 1.0 and rcp_ulp <= 1.5 and rsqrt_ulp <= 2.5, (log_ulp, sqrt_ulp, rcp_ulp, rsqrt_ulp)
 
 
+@pytest.mark.parametrize("group,L", [(3, (2, 2, 2, 2)), (3, (2, 6, 2, 2)), (3, (6, 10, 2, 4)), (3, (4, 34, 4, 4)),
+                                     (2, (2, 2, 2, 2)), (2, (10, 6, 6, 2))])
+def test_small_and_ragged_lattices(group, L):
+    """Smallest lattice, extents that leave workgroups partly empty and that no (z,t) region
+    cut divides, Ny/2 that does not divide the workgroup size: link by link against the checker."""
+    lat = ol.Lattice(group, L, 5.0 if group == 3 else 2.0, nhit=3, ints=1, rng_mode=ol.RNG_PERSITE, seed=13)
+    with _ctx(group=group, L=L, beta=5.0 if group == 3 else 2.0, nhit=3, rand_series=13) as c:
+        c.init_lattice()
+        for sweep in range(2):
+            c.sweep(1)
+            lat.sweep(1)
+            assert c.rng_draws() == ol.rng_draws(lat), sweep
+            assert np.max(np.abs(c.download() - lat.export_table())) < 1e-11, sweep
+        assert np.allclose(c.polyakov(), lat.polyakov(), rtol=1e-10, atol=1e-13)
+    lat.close()
+
+
 def test_config1_su3_16_plaquette_vs_cpu():
     """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)
