@@ -862,6 +862,46 @@ __device__ __forceinline__ double retr_plaquette(const double2* __restrict__ U, 
     return trace(p).re;
 }
 
+// SU(3), the form the kernel uses: ReTr[(U_mu(x) U_nu(x+mu)) (U_nu(x) U_mu(x+nu))^+], both
+// products SU(3) matrices, so two rows each come from products and the third from the cross
+// product (whose conjugation drops out of the real part).  Buffer addressing as in the update.
+__device__ __forceinline__ cplx cross_c(cplx a1, cplx a2, cplx b1, cplx b2)   // a1 b2 - a2 b1
+{
+    return csub(cmul(a1, b2), cmul(a2, b1));
+}
+// a = two rows of U_mu(x), d = two rows of U_nu(x) (kept by the caller: a site's four own links
+// serve three planes each), b = U_nu(x+mu), c = U_mu(x+nu) loaded here
+__device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__ U, const Geom& g, const int hb,
+                                                     const NbrOff& n, const int par, const int mu, const int nu,
+                                                     const rows2& a, const rows2& d)
+{
+    const raw_link rb = issue_link(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_fwd(n, mu));
+    const raw_link rc = issue_link(link_rsrc<3>(U, g, mu, par ^ 1), g, hb + off_fwd(n, nu));
+    const su3 b = as_su3(rb);
+    const su3 c = as_su3(rc);
+    cplx p[2][3], q[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            p[i][j] = dot3(a.e[i][0], a.e[i][1], a.e[i][2], b.e[0][j], b.e[1][j], b.e[2][j]);
+            q[i][j] = dot3(d.e[i][0], d.e[i][1], d.e[i][2], c.e[0][j], c.e[1][j], c.e[2][j]);
+        }
+    double re = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) re += p[i][j].re * q[i][j].re + p[i][j].im * q[i][j].im;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        const cplx cp = cross_c(p[0][j1], p[0][j2], p[1][j1], p[1][j2]);
+        const cplx cq = cross_c(q[0][j1], q[0][j2], q[1][j1], q[1][j2]);
+        re += cp.re * cq.re + cp.im * cq.im;
+    }
+    return re;
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void block_reduce_store(double a, double b, double2* __restrict__ partial)
 {
@@ -897,12 +937,26 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
     if (t < 2 * g.vh_int) {
         const int par = t / g.vh_int;
         const Site x = site_of(g, t - par * g.vh_int, par);
-        spat += retr_plaquette<GROUP>(U, g, x, 0, 1);
-        spat += retr_plaquette<GROUP>(U, g, x, 0, 2);
-        spat += retr_plaquette<GROUP>(U, g, x, 1, 2);
-        temp += retr_plaquette<GROUP>(U, g, x, 0, 3);
-        temp += retr_plaquette<GROUP>(U, g, x, 1, 3);
-        temp += retr_plaquette<GROUP>(U, g, x, 2, 3);
+        if constexpr (GROUP == 3) {
+            const int hb = half_index(g, x) * 16;
+            const NbrOff n = neighbour_offsets(g, x);
+            rows2 own[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) own[d] = as_rows2(issue_link(link_rsrc<3>(U, g, d, par), g, hb));
+            spat += retr_plaquette_su3(U, g, hb, n, par, 0, 1, own[0], own[1]);
+            spat += retr_plaquette_su3(U, g, hb, n, par, 0, 2, own[0], own[2]);
+            spat += retr_plaquette_su3(U, g, hb, n, par, 1, 2, own[1], own[2]);
+            temp += retr_plaquette_su3(U, g, hb, n, par, 0, 3, own[0], own[3]);
+            temp += retr_plaquette_su3(U, g, hb, n, par, 1, 3, own[1], own[3]);
+            temp += retr_plaquette_su3(U, g, hb, n, par, 2, 3, own[2], own[3]);
+        } else {
+            spat += retr_plaquette<GROUP>(U, g, x, 0, 1);
+            spat += retr_plaquette<GROUP>(U, g, x, 0, 2);
+            spat += retr_plaquette<GROUP>(U, g, x, 1, 2);
+            temp += retr_plaquette<GROUP>(U, g, x, 0, 3);
+            temp += retr_plaquette<GROUP>(U, g, x, 1, 3);
+            temp += retr_plaquette<GROUP>(U, g, x, 2, 3);
+        }
     }
     block_reduce_store<BLOCK>(spat, temp, partial);
 }
