@@ -92,6 +92,12 @@ int qcd_update(qcd_ctx *ctx, int parity, int dir);
  * Only valid for halo = 0 (a slab needs the halo exchange between passes). */
 int qcd_sweep(qcd_ctx *ctx, int n);
 
+/* Overrelaxation (microcanonical reflection in the three SU(2) subgroups, same pass structure
+ * and halo rule as qcd_update).  The reference has no overrelaxation: no call site to replace,
+ * and no reference output to pin it to -- it is checked by the invariance of the action. */
+int qcd_overrelax(qcd_ctx *ctx, int parity, int dir);
+int qcd_overrelax_sweep(qcd_ctx *ctx, int n);
+
 /* kernel_run(sun_GramSchmidt_id) (suncl.cpp:5376; kernel lattice_GramSchmidt, suncl.cl:349-396) */
 int qcd_reunitarize(qcd_ctx *ctx);
 

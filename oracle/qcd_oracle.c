@@ -524,6 +524,72 @@ void qo_update_link3(qo_su3 *U, const qo_su3 *stap, double beta, int nhit, int g
 }
 
 /* ------------------------------------------------------------------------- */
+/* Overrelaxation.  ABSENT from the reference ("parity unpinned"): built in the reference's own
+ * terms so that it slots into the same pass structure.  In the heat-bath the new SU(2) element
+ * is c * aH with aH = (M/det)^+ (update_su2.cpp:56-66) and c drawn at random; the microcanonical
+ * move reflects instead of drawing: c = aH, i.e. the element aH*aH.  Re Tr of the 2x2 block of
+ * U*A is unchanged by it, so the action is (to rounding) invariant: that is the test. */
+
+static void or_element2(const qo_su2 *stap, qo_su2 *out)
+{
+    double Mx = (stap->u1.re + stap->v2.re);
+    double My = (stap->u1.im - stap->v2.im);
+    double Mz = (stap->u2.re - stap->v1.re);
+    double Mw = (stap->u2.im + stap->v1.im);
+    double det = sqrt(Mx * Mx + My * My + Mz * Mz + Mw * Mw);
+    qo_su2 aH;
+    aH.u1.re =  Mx / det;
+    aH.u1.im = -My / det;
+    aH.u2.re = -Mz / det;
+    aH.u2.im = -Mw / det;
+    aH.v2.re =  aH.u1.re;
+    aH.v2.im = -aH.u1.im;
+    aH.v1.re = -aH.u2.re;
+    aH.v1.im =  aH.u2.im;
+    *out = qo_mul2(&aH, &aH);
+}
+
+/* SU(2): with W = U*A = c_old * det the reflection is c_new = c_old^+, i.e. U' = (aH_W aH_W) * U
+ * with aH_W = (W/det)^+ (equivalently U' = V^+ U^+ V^+, V = A/det) */
+void qo_overrelax_link2(qo_su2 *U, const qo_su2 *stap)
+{
+    qo_su2 W = qo_mul2(U, stap), r;
+    or_element2(&W, &r);
+    *U = qo_mul2(&r, U);
+}
+
+void qo_overrelax_link3(qo_su3 *U, const qo_su3 *stap)
+{
+    /* the three Cabibbo-Marinari subgroups in the heat-bath's order (update_su3.cpp:45-110) */
+    qo_su3 U0 = *U, x0, Vg;
+    qo_su2 b, r;
+
+    x0 = qo_mul3(&U0, stap);
+    b.u1 = x0.u1; b.u2 = x0.u2; b.v1 = x0.v1; b.v2 = x0.v2;
+    or_element2(&b, &r);
+    memset(&Vg, 0, sizeof(Vg));
+    Vg.u1 = r.u1; Vg.u2 = r.u2; Vg.v1 = r.v1; Vg.v2 = r.v2; Vg.w3.re = 1.0;
+    U0 = qo_mul3(&Vg, &U0);
+
+    x0 = qo_mul3(&U0, stap);
+    b.u1 = x0.u1; b.u2 = x0.u3; b.v1 = x0.w1; b.v2 = x0.w3;
+    or_element2(&b, &r);
+    memset(&Vg, 0, sizeof(Vg));
+    Vg.u1 = r.u1; Vg.u3 = r.u2; Vg.v2.re = 1.0; Vg.w1 = r.v1; Vg.w3 = r.v2;
+    U0 = qo_mul3(&Vg, &U0);
+
+    x0 = qo_mul3(&U0, stap);
+    b.u1 = x0.v2; b.u2 = x0.v3; b.v1 = x0.w2; b.v2 = x0.w3;
+    or_element2(&b, &r);
+    memset(&Vg, 0, sizeof(Vg));
+    Vg.u1.re = 1.0; Vg.v2 = r.u1; Vg.v3 = r.u2; Vg.w2 = r.v1; Vg.w3 = r.v2;
+    U0 = qo_mul3(&Vg, &U0);
+
+    qo_gram_schmidt3(&U0);
+    *U = U0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* staples and passes: SU(N)/suncpp/Update/sun_update.h                         */
 
 void qo_staple3(const qo_lattice *lat, int gid, int dir, qo_su3 *out)
@@ -641,6 +707,31 @@ void qo_update_pass_range(qo_lattice *lat, int parity, int dir, int x_begin, int
             tab[gid * nd + dir] = U;
         }
     }
+}
+
+void qo_overrelax_pass(qo_lattice *lat, int parity, int dir)
+{
+    const int nd = lat->nd;
+    for (int i = 0; i < lat->sites / 2; i++) {
+        int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
+        if (lat->group == 3) {
+            qo_su3 *tab = (qo_su3 *)lat->links;
+            qo_su3 stap;
+            qo_staple3(lat, gid, dir, &stap);
+            qo_overrelax_link3(&tab[gid * nd + dir], &stap);
+        } else {
+            qo_su2 *tab = (qo_su2 *)lat->links;
+            qo_su2 stap;
+            qo_staple2(lat, gid, dir, &stap);
+            qo_overrelax_link2(&tab[gid * nd + dir], &stap);
+        }
+    }
+}
+
+void qo_overrelax_sweep(qo_lattice *lat)
+{
+    for (int dir = 0; dir < 4; dir++) qo_overrelax_pass(lat, 1, dir);
+    for (int dir = 0; dir < 4; dir++) qo_overrelax_pass(lat, 0, dir);
 }
 
 void qo_sweep(qo_lattice *lat)

@@ -98,6 +98,11 @@ void qo_staple3(const qo_lattice *lat, int gid, int dir, qo_su3 *out);
 void qo_staple2(const qo_lattice *lat, int gid, int dir, qo_su2 *out);
 void qo_update_pass(qo_lattice *lat, int parity /*0 even, 1 odd*/, int dir);
 void qo_sweep(qo_lattice *lat);   /* odd X,Y,Z,T then even X,Y,Z,T */
+/* overrelaxation: not in the reference ("parity unpinned"); checked by the invariance of the action */
+void qo_overrelax_link3(qo_su3 *U, const qo_su3 *stap);
+void qo_overrelax_link2(qo_su2 *U, const qo_su2 *stap);
+void qo_overrelax_pass(qo_lattice *lat, int parity, int dir);
+void qo_overrelax_sweep(qo_lattice *lat);
 /* slab variants (x in [x_begin, x_end)) for the multi-rank tests */
 void qo_update_pass_range(qo_lattice *lat, int parity, int dir, int x_begin, int x_end);
 void qo_plaquette_sums_range(const qo_lattice *lat, int x_begin, int x_end, double out[2]);

@@ -125,6 +125,9 @@ class GpuSlabEngine:
     def update(self, parity, direction):
         self.ctx.update(parity, direction)
 
+    def overrelax(self, parity, direction):
+        self.ctx.overrelax(parity, direction)
+
     def halo_pack(self, side, direction, parity):
         buf = self._buf(("out", side))
         self.ctx.halo_pack(side, direction, parity, buf.data_ptr())
@@ -168,6 +171,16 @@ class BigLattice:
         for e in self.engines:
             e.update(parity, direction)
         self.comm.exchange(direction, parity)
+
+    def overrelax_sweep(self, n: int = 1):
+        """Microcanonical sweeps (no counterpart in the reference): same pass order and halo
+        traffic as the heat-bath sweep."""
+        for _ in range(n):
+            for parity in (1, 0):
+                for d in (X, Y, Z, T):
+                    for e in self.engines:
+                        e.overrelax(parity, d)
+                    self.comm.exchange(d, parity)
 
     def sweep(self, n: int = 1):
         # reference order: odd X,Y,Z,T then even X,Y,Z,T (SU(N)/suncpp/suncpp.h:133-141)
@@ -230,6 +243,9 @@ class LocalGpuEngine:
 
     def update(self, parity, direction):
         self.ctx.update(parity, direction)
+
+    def overrelax(self, parity, direction):
+        self.ctx.overrelax(parity, direction)
 
     def halo_pack(self, side, direction, parity):
         self.ctx.halo_pack(side, direction, parity, self.buf.data_ptr())

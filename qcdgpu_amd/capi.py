@@ -42,7 +42,8 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
-           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check"]
+           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
+           "qcd_overrelax", "qcd_overrelax_sweep"]
 
 
 def _load():
@@ -91,6 +92,8 @@ def _load():
     lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
     lib.qcd_prng_check.argtypes = [I, C.c_uint, I, I, I, C.POINTER(C.c_uint)]
     lib.qcd_math_check.argtypes = [I, I, C.POINTER(C.c_double)]
+    lib.qcd_overrelax.argtypes = [P, I, I]
+    lib.qcd_overrelax_sweep.argtypes = [P, I]
     lib.qcd_rng_state_bytes.restype = C.c_size_t
     lib.qcd_rng_state_bytes.argtypes = [P]
     lib.qcd_rng_state_download.argtypes = [P, C.c_void_p, C.c_size_t]
@@ -219,6 +222,12 @@ class Context:
         launches = C.c_ulonglong()
         _check(lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
         return ms.value, launches.value
+
+    def overrelax(self, parity, direction):
+        _check(lib.qcd_overrelax(self.h, parity, direction))
+
+    def overrelax_sweep(self, n=1):
+        _check(lib.qcd_overrelax_sweep(self.h, n))
 
     def rng_state(self):
         """The RANLUX streams' state as bytes (for checkpoints)."""

@@ -172,6 +172,20 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir)
     return QCD_OK;
 }
 
+template <int GROUP>
+int launch_overrelax(qcd_ctx* c, int parity, int dir)
+{
+    const Geom& g = c->g;
+    const dim3 grid(g.nzr * g.ntr * cdiv((long)g.nx * g.region_h, UPD_BLOCK)), block(UPD_BLOCK);
+    switch (dir) {
+        case 0: hipLaunchKernelGGL((k_overrelax<GROUP, 0, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
+        case 1: hipLaunchKernelGGL((k_overrelax<GROUP, 1, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
+        case 2: hipLaunchKernelGGL((k_overrelax<GROUP, 2, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
+        default: hipLaunchKernelGGL((k_overrelax<GROUP, 3, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
+    }
+    return QCD_OK;
+}
+
 int launch_update(qcd_ctx* c, int parity, int dir)
 {
     const bool gid = (c->p.start_mode == QCD_START_GID);
@@ -574,6 +588,31 @@ int qcd_update(qcd_ctx* c, int parity, int dir)
     if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
     if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
     return launch_update(c, parity, dir);
+}
+
+int qcd_overrelax(qcd_ctx* c, int parity, int dir)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    Timed tm(c, 0);
+    rc = (c->p.group == 3) ? launch_overrelax<3>(c, parity, dir) : launch_overrelax<2>(c, parity, dir);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return tm.finish();
+}
+
+int qcd_overrelax_sweep(qcd_ctx* c, int n)
+{
+    if (n < 0) return fail(QCD_ERR_INVALID, "n = %d", n);
+    for (int s = 0; s < n; s++)
+        for (int parity = 1; parity >= 0; parity--)
+            for (int dir = 0; dir < 4; dir++) {
+                const int rc = qcd_overrelax(c, parity, dir);
+                if (rc) return rc;
+            }
+    return QCD_OK;
 }
 
 int qcd_sweep(qcd_ctx* c, int n)

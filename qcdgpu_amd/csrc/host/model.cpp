@@ -154,6 +154,7 @@ void model::lattice_get_init_file(char* file)
         if (!strcmp(v, "PHI")) PHI = p.fVarVal;
         if (!strcmp(v, "OMEGA")) OMEGA = p.fVarVal;
         if (!strcmp(v, "NAV")) NAV = p.iVarVal;
+        if (!strcmp(v, "NOVERRELAX")) NOVERRELAX = p.iVarVal;   // extension: the reference has no overrelaxation
         if (!strcmp(v, "INTS"))
             ints = (p.iVarVal == 0) ? model_start_hot : (p.iVarVal == 2 ? model_start_gid : model_start_cold);
         if (!strcmp(v, "RANDSERIES") && !p.ivVarVal.empty()) rnds = p.ivVarVal;
@@ -318,6 +319,13 @@ void model::sweep(void)
             UpdateEdges(dir, parity);
             PRNG_counter++;
         }
+    // microcanonical sweeps after the heat-bath sweep (extension, NOVERRELAX = 0 by default)
+    for (int n = 0; n < NOVERRELAX; n++)
+        for (int parity = 1; parity >= 0; parity--)
+            for (int dir = 0; dir < 4; dir++) {
+                for (auto& s : SubLat) check(qcd_overrelax(s.ctx, parity, dir), "qcd_overrelax");
+                UpdateEdges(dir, parity);
+            }
 }
 
 void model::measure(int index)

@@ -104,6 +104,7 @@ public:
     int NITER = 1;
     int NHIT = 10;
     int NHITPar = 1;
+    int NOVERRELAX = 0;   // overrelaxation sweeps after every heat-bath sweep (not in the reference)
     double BETA = 6.5;
     double PHI = 0.0;
     double OMEGA = 0.0;

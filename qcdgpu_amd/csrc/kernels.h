@@ -409,6 +409,58 @@ __device__ __forceinline__ void update_link(su2& U, const su2& A, double beta, d
 }
 
 // ---------------------------------------------------------------------------------------------
+// Overrelaxation (microcanonical move).  The reference has none: this is the heat-bath's own
+// construction with the random element replaced by a reflection.  There the new SU(2) element is
+// c * aH, aH = (M/det)^+ (SU(N)/suncpp/su2/update_su2.cpp:56-66); here c = aH, the element
+// aH * aH, which leaves Re Tr of the 2x2 block of U*A -- hence the action -- unchanged.
+template <class Math>
+__device__ __forceinline__ su2 overrelax_su2(const su2& blk, const Math& m)
+{
+    const double Mx = (blk.e[0][0].re + blk.e[1][1].re);
+    const double My = (blk.e[0][0].im - blk.e[1][1].im);
+    const double Mz = (blk.e[0][1].re - blk.e[1][0].re);
+    const double Mw = (blk.e[0][1].im + blk.e[1][0].im);
+    double det, idet;
+    m.sqrt_rcp(Mx * Mx + My * My + Mz * Mz + Mw * Mw, det, idet);
+    su2 aH;
+    aH.e[0][0] = mk(Mx * idet, -My * idet);
+    aH.e[0][1] = mk(-Mz * idet, -Mw * idet);
+    aH.e[1][1] = mk(aH.e[0][0].re, -aH.e[0][0].im);
+    aH.e[1][0] = mk(-aH.e[0][1].re, aH.e[0][1].im);
+    return mul(aH, aH);
+}
+template <int P, int Q, class Math>
+__device__ __forceinline__ void cm_overrelax_step(su3& U, const su3& A, const Math& m)
+{
+    su2 blk;
+    blk.e[0][0] = dot3(U.e[P][0], U.e[P][1], U.e[P][2], A.e[0][P], A.e[1][P], A.e[2][P]);
+    blk.e[0][1] = dot3(U.e[P][0], U.e[P][1], U.e[P][2], A.e[0][Q], A.e[1][Q], A.e[2][Q]);
+    blk.e[1][0] = dot3(U.e[Q][0], U.e[Q][1], U.e[Q][2], A.e[0][P], A.e[1][P], A.e[2][P]);
+    blk.e[1][1] = dot3(U.e[Q][0], U.e[Q][1], U.e[Q][2], A.e[0][Q], A.e[1][Q], A.e[2][Q]);
+    const su2 r = overrelax_su2(blk, m);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const cplx up = U.e[P][j], uq = U.e[Q][j];
+        U.e[P][j] = dot2(r.e[0][0], r.e[0][1], up, uq);
+        U.e[Q][j] = dot2(r.e[1][0], r.e[1][1], up, uq);
+    }
+}
+template <class Math>
+__device__ __forceinline__ void overrelax_link(su3& U, const su3& A, const Math& m)
+{
+    cm_overrelax_step<0, 1>(U, A, m);
+    cm_overrelax_step<0, 2>(U, A, m);
+    cm_overrelax_step<1, 2>(U, A, m);
+    gram_schmidt(U, m);
+}
+template <class Math>
+__device__ __forceinline__ void overrelax_link(su2& U, const su2& A, const Math& m)
+{
+    const su2 r = overrelax_su2(mul(U, A), m);
+    U = mul(r, U);
+}
+
+// ---------------------------------------------------------------------------------------------
 // staple sum (SU(N)/suncpp/Update/sun_update.h:43-77): nu ascending, forward then backward
 
 // hb = 16 * half index of x, par = parity of x (wave-uniform)
@@ -843,6 +895,33 @@ __global__ __launch_bounds__(BLOCK) void k_update_redo(const UpdArgs a)
     }
     used = block_sum_u64<BLOCK>(used);
     if ((threadIdx.x & 63) == 0 && used) atomicAdd(a.draws, used);
+}
+
+// overrelaxation pass over the links of direction DIR on the sites of one parity: same gather
+// as the heat-bath pass, no random numbers
+template <int GROUP, int DIR, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 2) void k_overrelax(double2* __restrict__ U, const Geom g, const int parity)
+{
+    Site x;
+    int t;
+    if (!site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) return;
+    const int hb = half_index(g, x) * 16;
+    const NbrOff nbr = neighbour_offsets(g, x);
+    const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(U, g, DIR, parity);
+    MathFast fm;
+    fm.tab = nullptr;   // no logarithm on this path
+    mat<GROUP> A;
+    if constexpr (GROUP == 3) {
+        StaplePipe sp;
+        staple_pipe_head<DIR>(sp, U, g, hb, nbr, parity);
+        staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, NoHook());
+        A = sp.stap;
+    } else {
+        A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
+    }
+    mat<GROUP> Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
+    overrelax_link(Ul, A, fm);
+    store_link_buf(r_own, g, hb, Ul);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ def _load():
     lib.qo_init_links.argtypes = [P]
     lib.qo_sweep.argtypes = [P]
     lib.qo_update_pass.argtypes = [P, I, I]
+    lib.qo_overrelax_pass.argtypes = [P, I, I]
+    lib.qo_overrelax_sweep.argtypes = [P]
     lib.qo_plaquette.argtypes = [P, pd]
     lib.qo_action.argtypes = [P, pd]
     lib.qo_polyakov.argtypes = [P, pd]
@@ -98,6 +100,13 @@ class Lattice:
 
     def update(self, parity, direction):
         lib.qo_update_pass(self.h, parity, direction)
+
+    def overrelax(self, parity, direction):
+        lib.qo_overrelax_pass(self.h, parity, direction)
+
+    def overrelax_sweep(self, n=1):
+        for _ in range(n):
+            lib.qo_overrelax_sweep(self.h)
 
     def plaquette(self):
         out = (C.c_double * 3)()

@@ -93,6 +93,24 @@ def test_cli_hot_start_single_and_biglattice(tmp_path):
     lat.close()
 
 
+def test_cli_heatbath_plus_overrelaxation(tmp_path):
+    """NOVERRELAX (an init.dat key the reference does not have): k microcanonical sweeps after
+    every heat-bath sweep, single lattice = lattice in parts = the checker."""
+    keys = dict(GROUP=3, ND=4, L1=8, L2=4, L3=4, L4=6, BETA=6.0, NHIT=5, INTS=1, PRNG="RANLUX3",
+                RANDSERIES=9, NAV=1, ITER=3, NITER=1, NOVERRELAX=2)
+    _, _, single, _ = _run(tmp_path / "a", keys)
+    _, _, two, _ = _run(tmp_path / "b", keys, "\tN1 = {4, 4}\n\tDEVICE = {0, 0}\n")
+    assert np.max(np.abs(two - single)) < 1e-13
+    lat = ol.Lattice(3, (8, 4, 4, 6), 6.0, nhit=5, ints=1, rng_mode=ol.RNG_PERSITE, seed=9)
+    lat.sweep(1)                      # NAV = 1
+    lat.overrelax_sweep(2)
+    for sample in (1, 2):
+        lat.sweep(1)
+        lat.overrelax_sweep(2)
+        assert np.max(np.abs(single[sample, :3] - lat.plaquette()) / lat.plaquette()) < 1e-11
+    lat.close()
+
+
 def test_cli_state_file_resume_is_exact(tmp_path):
     """lattice_save_state / lattice_load_state: a run stopped after sample 2 and continued from
     its .qcg file gives the same table, digit for digit, as the uninterrupted run -- also when
@@ -159,6 +177,9 @@ def test_biglattice_python_driver_on_one_gpu():
             lat.sweep(1)
             assert np.max(np.abs(big.plaquette() - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-12
         assert np.allclose(big.polyakov(), lat.polyakov(), rtol=1e-10, atol=1e-13)
+        big.overrelax_sweep(1)          # microcanonical sweep across the slab boundaries
+        lat.overrelax_sweep(1)
+        assert np.max(np.abs(big.plaquette() - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-12
         draws = sum(e.ctx.rng_draws() for e in big.engines)
         assert draws == ol.rng_draws(lat)
         lat.close()

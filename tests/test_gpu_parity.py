@@ -192,6 +192,27 @@ def test_small_and_ragged_lattices(group, L):
     lat.close()
 
 
+@pytest.mark.parametrize("group,L,beta", [(3, (8, 8, 4, 6), 6.0), (2, (6, 8, 6, 4), 2.4)])
+def test_overrelaxation_matches_checker_and_keeps_the_action(group, L, beta):
+    """Heat-bath + overrelaxation (BASELINE config 2 names both; the reference has only the
+    heat-bath, so overrelaxation is parity unpinned): link by link against the checker's
+    restatement, and the plaquette average unchanged by microcanonical sweeps."""
+    lat = ol.Lattice(group, L, beta, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE, seed=19)
+    with _ctx(group=group, L=L, beta=beta, nhit=10, rand_series=19) as c:
+        c.init_lattice()
+        for sweep in range(2):
+            c.sweep(1)
+            lat.sweep(1)
+            p0 = c.plaquette()
+            c.overrelax_sweep(2)
+            lat.overrelax_sweep(2)
+            assert abs(c.plaquette()[2] - p0[2]) < 1e-13, sweep     # the total action
+            assert np.max(np.abs(c.download() - lat.export_table())) < 1e-10, sweep
+            assert _rel(c.plaquette(), lat.plaquette()) < REL
+        assert c.rng_draws() == ol.rng_draws(lat)       # no random numbers on that path
+    lat.close()
+
+
 def test_config1_su3_16_plaquette_vs_cpu():
     """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)

@@ -100,6 +100,20 @@ def test_hot_start_links_are_group_elements():
             l.close()
 
 
+def test_overrelaxation_keeps_the_action():
+    """Overrelaxation is not in the reference (parity unpinned): its defining property is that
+    every link move leaves Re Tr(U A), hence the plaquette average, unchanged."""
+    for group, beta in ((3, 6.0), (2, 2.5)):
+        lat = ol.Lattice(group, (4, 4, 6, 4), beta, ints=1, rng_mode=ol.RNG_PERSITE, seed=8)
+        lat.sweep(4)
+        p0, t0 = lat.plaquette(), lat.export_table().copy()
+        lat.overrelax_sweep(2)
+        p1, t1 = lat.plaquette(), lat.export_table()
+        assert abs(p1[2] - p0[2]) < 1e-13               # the total; space- and time-like parts trade
+        assert np.max(np.abs(t1 - t0)) > 0.5          # but the configuration moved, a lot
+        lat.close()
+
+
 def test_device_layout_roundtrip():
     for group in (2, 3):
         lat = ol.Lattice(group, (4, 4, 6, 4), 5.0, ints=2, rng_mode=ol.RNG_GID)
