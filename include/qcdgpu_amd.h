@@ -114,6 +114,11 @@ int qcd_measure_polyakov(qcd_ctx *ctx, double out[4]);
 int qcd_measure_plaquette_sums(qcd_ctx *ctx, double sums[2]);
 int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
 
+/* kernel_run(sun_measurement_wilson_id) + sun_wilson_loop_reduce_id (suncl.cpp:5266-5275): the
+ * R x T Wilson loop averaged over sites and the three space-time planes (denominator 3V,
+ * suncl.cpp:1606-1611).  One context owning the whole lattice only. */
+int qcd_measure_wilson(qcd_ctx *ctx, int R, int T, double *out);
+
 /* buffer_map / COPY_HOST_PTR of lattice_table (suncl.cpp:5498-5504, 3877-3991): the link table
  * of this context's slab in the REFERENCE device layout, double precision: rows of double4,
  * element [gindex + row*rowsize], gindex = y + z*Ny + t*Ny*Nz + x_local*Ny*Nz*Nt;

@@ -813,6 +813,67 @@ void qo_plaquette(const qo_lattice *lat, double out[3])
     out[1] = im / ((nd - 1) * lat->sites);                            /* Plq.h:92 */
 }
 
+/* Wilson loop W(R,T): device kernel lattice_measurement_wilson, SU(N)/suncl/wilson_loop.cl:54-453
+ * (no CPU twin in the reference: "parity unpinned"; W(1,1) is the time-like plaquette).  Per site p
+ * and spatial direction i: ReTr[ Tline(p) Rline_i(p + T t) Tline(p + R i)^+ Rline_i(p)^+ ] with
+ * Tline(q) = prod_{k<T} U_t(q + k t), Rline_i(q) = prod_{k<R} U_i(q + k i); average over 3 V
+ * (SU(N)/suncl/suncl.cpp:1606-1611, lattice_retrace_plaquette3, su3_measurements_cl.cl:527-547). */
+static qo_su3 line3(const qo_lattice *lat, int gid, int dir, int len, int *end)
+{
+    const qo_su3 *tab = (const qo_su3 *)lat->links;
+    qo_su3 m = tab[gid * lat->nd + dir];
+    for (int k = 1; k < len; k++) {
+        gid = qo_neighbour(lat->L, gid, dir);
+        m = qo_mul3(&m, &tab[gid * lat->nd + dir]);
+    }
+    *end = qo_neighbour(lat->L, gid, dir);
+    return m;
+}
+static qo_su2 line2(const qo_lattice *lat, int gid, int dir, int len, int *end)
+{
+    const qo_su2 *tab = (const qo_su2 *)lat->links;
+    qo_su2 m = tab[gid * lat->nd + dir];
+    for (int k = 1; k < len; k++) {
+        gid = qo_neighbour(lat->L, gid, dir);
+        m = qo_mul2(&m, &tab[gid * lat->nd + dir]);
+    }
+    *end = qo_neighbour(lat->L, gid, dir);
+    return m;
+}
+double qo_wilson_loop(const qo_lattice *lat, int R, int T)
+{
+    double sum = 0.0;
+    for (int gid = 0; gid < lat->sites; gid++) {
+        int pT, pR, dummy;
+        if (lat->group == 3) {
+            qo_su3 m1 = line3(lat, gid, 3, T, &pT);
+            for (int i = 0; i < 3; i++) {
+                qo_su3 m4 = line3(lat, gid, i, R, &pR);
+                qo_su3 m2 = line3(lat, pT, i, R, &dummy);
+                qo_su3 m3 = line3(lat, pR, 3, T, &dummy);
+                qo_su3 w = qo_mul3(&m1, &m2), h = qo_herm3(&m3);
+                w = qo_mul3(&w, &h);
+                h = qo_herm3(&m4);
+                w = qo_mul3(&w, &h);
+                sum += w.u1.re + w.v2.re + w.w3.re;
+            }
+        } else {
+            qo_su2 m1 = line2(lat, gid, 3, T, &pT);
+            for (int i = 0; i < 3; i++) {
+                qo_su2 m4 = line2(lat, gid, i, R, &pR);
+                qo_su2 m2 = line2(lat, pT, i, R, &dummy);
+                qo_su2 m3 = line2(lat, pR, 3, T, &dummy);
+                qo_su2 w = qo_mul2(&m1, &m2), h = qo_herm2(&m3);
+                w = qo_mul2(&w, &h);
+                h = qo_herm2(&m4);
+                w = qo_mul2(&w, &h);
+                sum += w.u1.re + w.v2.re;
+            }
+        }
+    }
+    return sum / (3.0 * lat->sites);
+}
+
 void qo_action(const qo_lattice *lat, double out[3])
 {
     const int nd = lat->nd;

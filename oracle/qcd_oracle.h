@@ -118,6 +118,8 @@ void qo_update_link2(qo_su2 *a, const qo_su2 *stap, double beta_eff, int nhit, i
 /* measurements: out[0]=spat, out[1]=temp, out[2]=total */
 void qo_plaquette(const qo_lattice *lat, double out[3]);
 void qo_action(const qo_lattice *lat, double out[3]);
+/* Wilson loop W(R,T) average (device path of the reference only: "parity unpinned") */
+double qo_wilson_loop(const qo_lattice *lat, int R, int T);
 /* out = Re P, Im P, |P|^2, |P|^4 averages; "parity unpinned" */
 void qo_polyakov(const qo_lattice *lat, double out[4]);
 

@@ -677,6 +677,27 @@ int qcd_measure_action(qcd_ctx* c, double out[3])
     return QCD_OK;
 }
 
+int qcd_measure_wilson(qcd_ctx* c, int R, int T, double* out)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (!out) return fail(QCD_ERR_INVALID, "null output");
+    if (R < 1 || T < 1) return fail(QCD_ERR_INVALID, "Wilson loop %d x %d", R, T);
+    if (c->g.halo) return fail(QCD_ERR_UNSUPPORTED, "Wilson loop on a slab: lines of length R leave the one-slice halo");
+    const int nb = cdiv(2L * c->g.vh_int, MEAS_BLOCK);
+    if (nb > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
+    Timed tm(c, 1);
+    const dim3 grid(nb), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_wilson<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, R, T, c->partial);
+    else hipLaunchKernelGGL((k_wilson<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, R, T, c->partial);
+    if ((rc = tm.finish())) return rc;
+    double s[2];
+    rc = reduce_partials(c, nb, 1, s);
+    if (rc) return rc;
+    *out = s[0] / (3.0 * (double)c->g.gsites);   // SU(N)/suncl/suncl.cpp:1606-1611
+    return QCD_OK;
+}
+
 int qcd_measure_polyakov_sums(qcd_ctx* c, double sums[4])
 {
     int rc = check_ctx(c, true);

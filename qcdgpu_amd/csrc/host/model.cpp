@@ -254,6 +254,7 @@ void model::lattice_init(void)
     if (lattice_nd != 4) throw model_error("ND must be 4");
     if (precision != model_precision_double) throw model_error("only double precision is implemented");
     if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
+    if (get_wilson_loop && lattice_Nparts > 1) throw model_error("the Wilson loop is measured on an uncut lattice only (GETWILSON with N1 = {..})");
     // initialize_CPU (SU(N)/random/random.cpp:174-182): RANDSERIES = 0 means "seed from the clock"
     PRNG0->PRNG_srandtime = (unsigned int)time(NULL);
     if (!PRNG0->PRNG_randseries) PRNG0->PRNG_randseries = PRNG0->PRNG_srandtime;
@@ -345,6 +346,7 @@ void model::measure(int index)
     }
     for (int i = 0; i < 2; i++) plq_raw_[i][index] = plq[i];
     for (int i = 0; i < 4; i++) pl_raw_[i][index] = pl[i];
+    if (get_wilson_loop) check(qcd_measure_wilson(SubLat[0].ctx, wilson_R, wilson_T, &wl_[index]), "qcd_measure_wilson");
     derive_sample(index);
 }
 
@@ -443,7 +445,7 @@ std::vector<unsigned int> model::lattice_make_bin_header(void) const   // suncl.
     r[k++] = 0u;   // get_Fmunu
     r[k++] = get_actions_avr ? 1u : 0u;
     r[k++] = get_plaquettes_avr ? 1u : 0u;
-    r[k++] = 0u;   // get_wilson_loop
+    r[k++] = get_wilson_loop ? 1u : 0u;
     r[k++] = 0u;   // lattice_measurement_size_F: the reduce scratch buffer is not part of this engine's state
     r[k++] = energies_size();
     r[k++] = energies_size();   // lattice_energies_size_F (no F_mu_nu)
@@ -489,7 +491,7 @@ bool model::lattice_load_bin_header(const unsigned int* head)   // suncl.cpp:199
     if (head[k++] != 0u) return false;   // F_mu_nu sections are not written or read by this engine
     get_actions_avr = head[k++] != 0;
     get_plaquettes_avr = head[k++] != 0;
-    if (head[k++] != 0u) return false;   // nor the Wilson loop section
+    get_wilson_loop = head[k++] != 0;
     state_sizes_[0] = head[k++];
     state_sizes_[1] = head[k++];
     state_sizes_[2] = head[k++];
@@ -529,6 +531,11 @@ void model::lattice_save_state(void)
     };
     write_pairs(act_[0], act_[1], 3.0 * v);                               // lattice_energies: S x its denominator (suncl.cpp:1340-1348)
     if (get_plaquettes_avr) write_pairs(plq_raw_[0], plq_raw_[1], 1.0);   // lattice_energies_plq: lattice sums
+    if (get_wilson_loop) {                                                // lattice_wilson_loop: doubles, sums over 3V
+        std::vector<double> w((size_t)es, 0.0);
+        for (int i = 0; i < ITER_counter && i < ITER; i++) w[i] = wl_[i] * 3.0 * v;
+        fwrite(w.data(), sizeof(double), es, stream);
+    }
     if (PL_level > 0) write_pairs(pl_raw_[0], pl_raw_[1], 1.0);           // lattice_polyakov_loop: Re, Im sums
 
     // link table: rows of the whole lattice, each part's sites at their global position
@@ -620,6 +627,11 @@ void model::lattice_load_state(void)
     else
         for (int i = 0; i < ITER_counter && i < ITER; i++)   // plaquette sums back from S = beta (1 - Plq / N)
             for (int c = 0; c < 2; c++) plq_raw_[c][i] = 3.0 * v * g * (1.0 - s_raw[c][i] / (3.0 * v) / BETA);
+    if (get_wilson_loop) {                                                              // lattice_wilson_loop
+        std::vector<double> w((size_t)state_sizes_[1], 0.0);
+        ok = ok && fread(w.data(), sizeof(double), w.size(), stream) == w.size();
+        for (int i = 0; i < ITER_counter && i < ITER && (size_t)i < w.size(); i++) wl_[i] = w[i] / (3.0 * v);
+    }
     if (PL_level > 0) read_pairs(state_sizes_[3], &pl_raw_[0], &pl_raw_[1]);            // lattice_polyakov_loop
     const int rows = (lattice_group == 3) ? 12 : 4;
     const unsigned int rs = table_row_size();
@@ -701,6 +713,7 @@ void model::lattice_simulate(void)
     for (int i = 0; i < 4; i++) pl_[i].assign(ITER, 0.0);
     for (int i = 0; i < 2; i++) plq_raw_[i].assign(ITER, 0.0);
     for (int i = 0; i < 4; i++) pl_raw_[i].assign(ITER, 0.0);
+    wl_.assign(ITER, 0.0);
 
     free(timestart);
     timestart = current_datetime(&ltimestart);
@@ -763,6 +776,8 @@ void model::lattice_analysis(void)
     Analysis[DM_Polyakov_loop_im].data = pl_[1];
     Analysis[DM_Polyakov_loop_P2].data = pl_[2];
     Analysis[DM_Polyakov_loop_P4].data = pl_[3];
+    Analysis[DM_Wilson_loop].data = wl_;
+    lattice_data_analysis(&Analysis[DM_Wilson_loop]);
     for (int i = 1; i <= DM_max; i++) lattice_data_analysis(&Analysis[i]);
 }
 
@@ -786,6 +801,10 @@ const char* model::lattice_make_header2(void)
     for (int idx : order) {
         j += snprintf(buf + j, n - j, " Mean %-20s: % 16.13e\n", Analysis[idx].data_name, Analysis[idx].mean_value);
         j += snprintf(buf + j, n - j, " Variance %-16s: % 16.13e\n", Analysis[idx].data_name, Analysis[idx].variance);
+    }
+    if (get_wilson_loop) {
+        j += snprintf(buf + j, n - j, " Mean %-20s: % 16.13e\n", Analysis[DM_Wilson_loop].data_name, Analysis[DM_Wilson_loop].mean_value);
+        j += snprintf(buf + j, n - j, " Variance %-16s: % 16.13e\n", Analysis[DM_Wilson_loop].data_name, Analysis[DM_Wilson_loop].variance);
     }
     j += snprintf(buf + j, n - j, " ***************************************************\n");
     for (int idx : order)
@@ -812,6 +831,7 @@ void model::lattice_write_results(void)
     fprintf(stream, "    #,  ");
     std::vector<int> cols;
     if (get_plaquettes_avr) { cols.push_back(DM_Plq_spat); cols.push_back(DM_Plq_temp); cols.push_back(DM_Plq_total); }
+    if (get_wilson_loop) cols.push_back(DM_Wilson_loop);   // column order of SU(N)/suncl/suncl.cpp:1796-1818
     if (get_actions_avr) { cols.push_back(DM_S_spat); cols.push_back(DM_S_temp); cols.push_back(DM_S_total); }
     if (PL_level > 0) { cols.push_back(DM_Polyakov_loop); cols.push_back(DM_Polyakov_loop_im); }
     if (PL_level > 1) { cols.push_back(DM_Polyakov_loop_P2); cols.push_back(DM_Polyakov_loop_P4); }
@@ -833,6 +853,7 @@ void model::lattice_print_measurements(void)
     if (get_plaquettes_avr) printf(" %-11s %-11s", Analysis[DM_Plq_spat].data_name, Analysis[DM_Plq_temp].data_name);
     if (get_actions_avr) printf(" %-11s %-11s", Analysis[DM_S_spat].data_name, Analysis[DM_S_temp].data_name);
     if (PL_level > 0) printf(" %-11s %-11s", Analysis[DM_Polyakov_loop].data_name, Analysis[DM_Polyakov_loop_im].data_name);
+    if (get_wilson_loop) printf(" %-11s", Analysis[DM_Wilson_loop].data_name);
     printf("\n");
     for (int i = 0; i < ITER; i++) {
         if ((i < 5) || (i == (ITER - 1))) {
@@ -840,6 +861,7 @@ void model::lattice_print_measurements(void)
             if (get_plaquettes_avr) printf(" % 10.8f % 10.8f", Analysis[DM_Plq_spat].data[i], Analysis[DM_Plq_temp].data[i]);
             if (get_actions_avr) printf(" % 10.8f % 10.8f", Analysis[DM_S_spat].data[i], Analysis[DM_S_temp].data[i]);
             if (PL_level > 0) printf(" % 10.8f % 10.8f", Analysis[DM_Polyakov_loop].data[i], Analysis[DM_Polyakov_loop_im].data[i]);
+            if (get_wilson_loop) printf(" % 10.8f", Analysis[DM_Wilson_loop].data[i]);
             printf("\n");
         }
     }

@@ -120,7 +120,7 @@ public:
     bool turnoff_gramschmidt = false;
     bool get_actions_avr = true;
     bool get_plaquettes_avr = true;
-    bool get_wilson_loop = false;  // accepted from init.dat, not measured by this engine
+    bool get_wilson_loop = false;  // GETWILSON: the wilson_R x wilson_T loop as a further column
     bool profiling = false;        // GPU_debug.profiling
     // lattice state files (SU(N)/suncl/suncl.h:80,154-175; defaults of main, QCDGPU.cpp:203,215)
     bool turnoff_config_save = true;                 // do not write configurations
@@ -170,6 +170,7 @@ public:
 
 private:
     std::vector<double> plq_[3], act_[3], pl_[4];
+    std::vector<double> wl_;
     std::vector<double> plq_raw_[2], pl_raw_[4];   // per sample: the lattice sums the table entries derive from
     void derive_sample(int index);
     std::string device_names_;

@@ -1072,6 +1072,46 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double2* __restrict__ pa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wilson loop W(R,T) (kernel lattice_measurement_wilson, SU(N)/suncl/wilson_loop.cl:54-453): per
+// site p and spatial direction i, ReTr[Tline(p) Rline_i(p + T t) Tline(p + R i)^+ Rline_i(p)^+].
+// partial[block] = (sum over the block's sites and the three directions, 0)
+
+template <int GROUP>
+__device__ __forceinline__ mat<GROUP> link_line(const double2* __restrict__ U, const Geom& g, Site& q, int dir, int len)
+{
+    mat<GROUP> m = load_site_link<GROUP>(U, g, dir, q);
+    for (int k = 1; k < len; k++) {
+        q = fwd(g, q, dir);
+        m = mul(m, load_site_link<GROUP>(U, g, dir, q));
+    }
+    q = fwd(g, q, dir);   // the site behind the line's end
+    return m;
+}
+
+template <int GROUP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_wilson(const double2* __restrict__ U, const Geom g, const int R, const int T,
+                                                  double2* __restrict__ partial)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    double sum = 0.0;
+    if (t < 2 * g.vh_int) {
+        const int par = t / g.vh_int;
+        const Site p = site_of(g, t - par * g.vh_int, par);
+        Site pT = p;
+        const mat<GROUP> m1 = link_line<GROUP>(U, g, pT, 3, T);
+#pragma unroll 1
+        for (int i = 0; i < 3; i++) {
+            Site pR = p, q2 = pT;
+            const mat<GROUP> m4 = link_line<GROUP>(U, g, pR, i, R);
+            const mat<GROUP> m2 = link_line<GROUP>(U, g, q2, i, R);
+            const mat<GROUP> m3 = link_line<GROUP>(U, g, pR, 3, T);
+            sum += trace(mul(mul(mul(m1, m2), herm(m3)), herm(m4))).re;
+        }
+    }
+    block_reduce_store<BLOCK>(sum, 0.0, partial);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Polyakov loop (SU(N)/suncl/su3cpu.cpp:1383-1433; kernel lattice_polyakov,
 // SU(N)/suncl/polyakov.cl:53-141): P = Tr prod_{t=0}^{Nt-1} U_T(x,t), left to right from t = 0.
 // partial[0][block] = (sum Re P, sum Im P), partial[1][block] = (sum |P|^2, sum |P|^4)

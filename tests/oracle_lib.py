@@ -31,6 +31,8 @@ def _load():
     lib.qo_update_pass.argtypes = [P, I, I]
     lib.qo_overrelax_pass.argtypes = [P, I, I]
     lib.qo_overrelax_sweep.argtypes = [P]
+    lib.qo_wilson_loop.argtypes = [P, I, I]
+    lib.qo_wilson_loop.restype = C.c_double
     lib.qo_plaquette.argtypes = [P, pd]
     lib.qo_action.argtypes = [P, pd]
     lib.qo_polyakov.argtypes = [P, pd]
@@ -117,6 +119,9 @@ class Lattice:
         out = (C.c_double * 3)()
         lib.qo_action(self.h, out)
         return np.array(out[:])
+
+    def wilson_loop(self, R, T):
+        return lib.qo_wilson_loop(self.h, R, T)
 
     def polyakov(self):
         out = (C.c_double * 4)()

@@ -111,6 +111,27 @@ def test_cli_heatbath_plus_overrelaxation(tmp_path):
     lat.close()
 
 
+def test_cli_wilson_loop_column(tmp_path):
+    """GETWILSON adds the WILSONR x WILSONT loop as the column behind the plaquettes, as in the
+    reference's result file; it survives a stop and --load."""
+    keys = dict(GROUP=2, ND=4, L1=6, L2=4, L3=4, L4=6, BETA=2.3, NHIT=5, INTS=1, PRNG="RANLUX3",
+                RANDSERIES=17, NAV=1, ITER=4, NITER=1, GETWILSON=1, WILSONR=2, WILSONT=3)
+    text, fields, rows, _ = _run(tmp_path / "a", keys)
+    assert fields[:4] == ["Plq_spat", "Plq_temp", "Plq_total", "Wilson_loop"] and " Mean Wilson_loop" in text
+    lat = ol.Lattice(2, (6, 4, 4, 6), 2.3, nhit=5, ints=1, rng_mode=ol.RNG_PERSITE, seed=17)
+    assert rows[0, 3] == 2.0
+    lat.sweep(2)
+    assert abs(rows[1, 3] - lat.wilson_loop(2, 3)) < 1e-12
+    lat.close()
+    _, _, none, out = _run(tmp_path / "b", keys, args=["--save-state", "--save-every", "1e9", "--stop-at", "2"])
+    qcg = re.findall(r"state file: (\S+)", out)[-1]
+    import shutil
+    (tmp_path / "c").mkdir()
+    shutil.copy(qcg, tmp_path / "c" / "s.qcg")
+    _, _, resumed, _ = _run(tmp_path / "c", keys, args=["--load", "s.qcg"])
+    assert np.array_equal(resumed, rows)
+
+
 def test_cli_state_file_resume_is_exact(tmp_path):
     """lattice_save_state / lattice_load_state: a run stopped after sample 2 and continued from
     its .qcg file gives the same table, digit for digit, as the uninterrupted run -- also when

@@ -213,6 +213,27 @@ def test_overrelaxation_matches_checker_and_keeps_the_action(group, L, beta):
     lat.close()
 
 
+@pytest.mark.parametrize("group,L,beta", [(3, (6, 4, 8, 6), 6.0), (2, (4, 8, 6, 6), 2.4)])
+def test_wilson_loop_matches_checker(group, L, beta):
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    lat = ol.Lattice(group, L, beta, nhit=5, ints=1, rng_mode=ol.RNG_PERSITE, seed=23)
+    with _ctx(group=group, L=L, beta=beta, nhit=5, rand_series=23) as c:
+        c.init_lattice()
+        assert c.wilson_loop(3, 2) == float(group)
+        c.sweep(2)
+        lat.sweep(2)
+        assert abs(c.wilson_loop(1, 1) - c.plaquette()[1]) < 1e-13
+        for R, T in ((1, 1), (2, 1), (1, 3), (2, 2), (3, 4), (5, 7)):     # the last ones wrap around
+            assert abs(c.wilson_loop(R, T) - lat.wilson_loop(R, T)) < 1e-12, (R, T)
+        with pytest.raises(q.QcdError):
+            c.wilson_loop(0, 1)
+    lat.close()
+    big = bl.make_gpu_slabs(group, L, beta, [2, L[0] - 2], nhit=5, rand_series=23)
+    with pytest.raises(q.QcdError):
+        big.engines[0].ctx.wilson_loop(1, 1)                               # not on a slab
+
+
 def test_config1_su3_16_plaquette_vs_cpu():
     """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)

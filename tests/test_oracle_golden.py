@@ -114,6 +114,18 @@ def test_overrelaxation_keeps_the_action():
         lat.close()
 
 
+def test_wilson_loop_known_answers():
+    """W(R,T) (device path of the reference only: parity unpinned): cold start gives N, the 1x1
+    loop is the time-like plaquette, and larger loops are smaller on a thermalised lattice."""
+    for group, beta in ((3, 6.0), (2, 2.5)):
+        lat = ol.Lattice(group, (4, 6, 4, 6), beta, ints=1, rng_mode=ol.RNG_PERSITE, seed=4)
+        assert lat.wilson_loop(2, 3) == float(group)
+        lat.sweep(3)
+        assert abs(lat.wilson_loop(1, 1) - lat.plaquette()[1]) < 1e-14
+        assert lat.wilson_loop(1, 1) > lat.wilson_loop(2, 1) > lat.wilson_loop(2, 2) > lat.wilson_loop(3, 3) > 0
+        lat.close()
+
+
 def test_device_layout_roundtrip():
     for group in (2, 3):
         lat = ol.Lattice(group, (4, 4, 6, 4), 5.0, ints=2, rng_mode=ol.RNG_GID)
