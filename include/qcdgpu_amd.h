@@ -92,6 +92,12 @@ int qcd_update(qcd_ctx *ctx, int parity, int dir);
  * Only valid for halo = 0 (a slab needs the halo exchange between passes). */
 int qcd_sweep(qcd_ctx *ctx, int n);
 
+/* qcd_update restricted to xs_count owned x-slices starting at xs_begin (wrapping around the owned
+ * range).  No counterpart in the reference, which updates a part as a whole and then copies its
+ * edges (suncl.cpp:5026-5138): a slab updates its boundary slices first and sends them while the
+ * interior is being updated.  The ranges of one pass must tile the slab exactly once. */
+int qcd_update_range(qcd_ctx *ctx, int parity, int dir, int xs_begin, int xs_count);
+
 /* Overrelaxation (microcanonical reflection in the three SU(2) subgroups, same pass structure
  * and halo rule as qcd_update).  The reference has no overrelaxation: no call site to replace,
  * and no reference output to pin it to -- it is checked by the invariance of the action. */

@@ -43,7 +43,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
            "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
-           "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson"]
+           "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range"]
 
 
 def _load():
@@ -93,6 +93,7 @@ def _load():
     lib.qcd_prng_check.argtypes = [I, C.c_uint, I, I, I, C.POINTER(C.c_uint)]
     lib.qcd_math_check.argtypes = [I, I, C.POINTER(C.c_double)]
     lib.qcd_overrelax.argtypes = [P, I, I]
+    lib.qcd_update_range.argtypes = [P, I, I, I, I]
     lib.qcd_measure_wilson.argtypes = [P, I, I, C.POINTER(C.c_double)]
     lib.qcd_overrelax_sweep.argtypes = [P, I]
     lib.qcd_rng_state_bytes.restype = C.c_size_t
@@ -223,6 +224,9 @@ class Context:
         launches = C.c_ulonglong()
         _check(lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
         return ms.value, launches.value
+
+    def update_range(self, parity, direction, xs_begin, xs_count):
+        _check(lib.qcd_update_range(self.h, parity, direction, xs_begin, xs_count))
 
     def wilson_loop(self, R, T):
         out = C.c_double()

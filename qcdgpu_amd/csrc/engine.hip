@@ -120,11 +120,13 @@ struct Timed {
 // NSKIP: 223 = RANLUX3 (the reference's default, QCDGPU.cpp:98) with the skip unrolled at compile
 // time; 0 = any luxury level, skip count at run time
 template <int GROUP, bool GID, int NSKIP>
-int launch_update_dir(qcd_ctx* c, int parity, int dir)
+int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count)
 {
-    const Geom& g = c->g;
+    Geom g = c->g;
+    g.ux0 = xs_begin;
+    g.unx = xs_count;
     const int regions = g.nzr * g.ntr;
-    const int nblocks = regions * (int)cdiv((long)g.nx * g.region_h, UPD_BLOCK);
+    const int nblocks = regions * (int)cdiv((long)g.unx * g.region_h, UPD_BLOCK);
     // launch no more workgroups than the device holds at one time and let each walk several
     // blocks of sites: a finished wave goes straight on to its next site instead of waiting for
     // its stores to drain and for the dispatcher to start a successor
@@ -186,19 +188,19 @@ int launch_overrelax(qcd_ctx* c, int parity, int dir)
     return QCD_OK;
 }
 
-int launch_update(qcd_ctx* c, int parity, int dir)
+int launch_update(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count)
 {
     const bool gid = (c->p.start_mode == QCD_START_GID);
     const bool lux3 = (c->p.lux_level == 3);
     Timed tm(c, 0);
     if (c->p.group == 3) {
-        if (gid) launch_update_dir<3, true, 0>(c, parity, dir);
-        else if (lux3) launch_update_dir<3, false, 223>(c, parity, dir);
-        else launch_update_dir<3, false, 0>(c, parity, dir);
+        if (gid) launch_update_dir<3, true, 0>(c, parity, dir, xs_begin, xs_count);
+        else if (lux3) launch_update_dir<3, false, 223>(c, parity, dir, xs_begin, xs_count);
+        else launch_update_dir<3, false, 0>(c, parity, dir, xs_begin, xs_count);
     } else {
-        if (gid) launch_update_dir<2, true, 0>(c, parity, dir);
-        else if (lux3) launch_update_dir<2, false, 223>(c, parity, dir);
-        else launch_update_dir<2, false, 0>(c, parity, dir);
+        if (gid) launch_update_dir<2, true, 0>(c, parity, dir, xs_begin, xs_count);
+        else if (lux3) launch_update_dir<2, false, 223>(c, parity, dir, xs_begin, xs_count);
+        else launch_update_dir<2, false, 0>(c, parity, dir, xs_begin, xs_count);
     }
     return tm.finish();
 }
@@ -427,6 +429,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     g.rt = g.nt / g.ntr;
     g.region_h = g.nyh * g.rz * g.rt;
     g.tz = g.tt = g.tx = 0;
+    g.ux0 = 0;
+    g.unx = g.nx;
     if (const char* ov = getenv("QCDGPU_AMD_TILE")) {  // diagnostic override "tz,tt,tx"
         int a = 0, b = 0, d = 0;
         if (sscanf(ov, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0 && UPD_BLOCK % g.nyh == 0 &&
@@ -587,7 +591,18 @@ int qcd_update(qcd_ctx* c, int parity, int dir)
     if (rc) return rc;
     if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
     if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
-    return launch_update(c, parity, dir);
+    return launch_update(c, parity, dir, 0, c->g.nx);
+}
+
+int qcd_update_range(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    if (xs_begin < 0 || xs_begin >= c->g.nx || xs_count < 1 || xs_count > c->g.nx)
+        return fail(QCD_ERR_INVALID, "slice range %d + %d of %d owned slices", xs_begin, xs_count, c->g.nx);
+    return launch_update(c, parity, dir, xs_begin, xs_count);
 }
 
 int qcd_overrelax(qcd_ctx* c, int parity, int dir)
@@ -622,9 +637,9 @@ int qcd_sweep(qcd_ctx* c, int n)
     if (c->g.halo) return fail(QCD_ERR_STATE, "qcd_sweep on a slab context: the halo exchange between passes is the caller's");
     for (int s = 0; s < n; s++) {
         for (int dir = 0; dir < 4; dir++)
-            if ((rc = launch_update(c, 1, dir))) return rc;
+            if ((rc = launch_update(c, 1, dir, 0, c->g.nx))) return rc;
         for (int dir = 0; dir < 4; dir++)
-            if ((rc = launch_update(c, 0, dir))) return rc;
+            if ((rc = launch_update(c, 0, dir, 0, c->g.nx))) return rc;
     }
     return QCD_OK;
 }

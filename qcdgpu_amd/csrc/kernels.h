@@ -773,6 +773,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     g.vh_int = ap->g.vh_int; g.vh_alloc = ap->g.vh_alloc; g.gsites = ap->g.gsites; g.gslice = ap->g.gslice;
     g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h;
     g.tz = ap->g.tz; g.tt = ap->g.tt; g.tx = ap->g.tx;
+    g.ux0 = ap->g.ux0; g.unx = ap->g.unx;
     const int parity = ap->parity;
     const int nhit = ap->nhit;
     const double beta_eff = ap->beta_eff;

@@ -44,6 +44,10 @@ struct Geom {
     // shape of the block of sites one workgroup updates inside its region: all of y times
     // tz x tt x tx sites in z, t, x (tz = 0: a run of consecutive half-sites, y then z then t)
     int tz, tt, tx;
+    // x-slices an update launch works on: unx slices starting at owned slice ux0, wrapping around
+    // the owned range (ux0 = 0, unx = nx: the whole slab).  Lets a slab update its boundary
+    // slices first, so that their halo messages travel while the interior is updated.
+    int ux0, unx;
 };
 
 struct Site {
@@ -95,7 +99,7 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
         T /= ntz;
         const int Tt = T % ntt;
         const int Tx = T / ntt;
-        if (Tx * g.tx >= g.nx) return false;
+        if (Tx * g.tx >= g.unx) return false;
         yh = tid % g.nyh;
         int r = tid / g.nyh;
         zl = Tz * g.tz + r % g.tz;
@@ -104,7 +108,7 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
         s.xs = Tx * g.tx + r / g.tt;
     } else {
         const int w = (b / regions) * BLOCK + tid;
-        if (w >= g.nx * g.region_h) return false;
+        if (w >= g.unx * g.region_h) return false;
         s.xs = w / g.region_h;
         int q = w - s.xs * g.region_h;
         const int plane = g.nyh * g.rz;
@@ -113,6 +117,8 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
         zl = q / g.nyh;
         yh = q - zl * g.nyh;
     }
+    s.xs += g.ux0;   // position inside the launch's slice range -> owned slice, wrapping
+    if (s.xs >= g.nx) s.xs -= g.nx;
     s.z = (k % g.nzr) * g.rz + zl;
     s.t = (k / g.nzr) * g.rt + tl;
     const int yb = (par + g.x0 + s.xs + s.z + s.t) & 1;

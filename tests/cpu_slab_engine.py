@@ -40,6 +40,13 @@ class CpuSlabEngine:
     def update(self, parity, direction):
         ol.lib.qo_update_pass_range(self.lat.h, parity, direction, self.x0, self.x0 + self.nx)
 
+    def update_range(self, parity, direction, xs_begin, xs_count):
+        # slices xs_begin .. xs_begin + xs_count - 1 of this slab, wrapping around its owned range
+        first = min(xs_count, self.nx - xs_begin)
+        ol.lib.qo_update_pass_range(self.lat.h, parity, direction, self.x0 + xs_begin, self.x0 + xs_begin + first)
+        if xs_count > first:
+            ol.lib.qo_update_pass_range(self.lat.h, parity, direction, self.x0, self.x0 + xs_count - first)
+
     def _sel(self, x, parity):
         return ((self.yzt_parity + x) & 1) == parity
 

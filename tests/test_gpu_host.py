@@ -206,6 +206,31 @@ def test_biglattice_python_driver_on_one_gpu():
         lat.close()
 
 
+def test_biglattice_boundary_first_update_on_one_gpu():
+    """Slabs wide enough for the split pass: boundary slices (two deep here), halo messages,
+    then the interior -- same configuration as the uncut lattice, and the range entry point
+    rejects ranges outside the slab."""
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    L = (16, 4, 4, 6)
+    lat = ol.Lattice(3, L, 5.8, nhit=4, ints=1, rng_mode=ol.RNG_PERSITE, seed=29)
+    big = bl.make_gpu_slabs(3, L, 5.8, [8, 8], nhit=4, rand_series=29)
+    assert big.boundary_depth() == 2                 # a quarter of the narrowest slab
+    for s in range(2):
+        big.sweep(1)
+        lat.sweep(1)
+        assert np.max(np.abs(big.plaquette() - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-12
+    assert sum(e.ctx.rng_draws() for e in big.engines) == ol.rng_draws(lat)
+    got = np.concatenate([e.ctx.download() for e in big.engines], axis=1)
+    want = lat.export_table()
+    assert np.max(np.abs(got - want)) < 1e-11
+    with pytest.raises(q.QcdError):
+        big.engines[0].ctx.update_range(0, 0, 8, 1)
+    with pytest.raises(q.QcdError):
+        big.engines[0].ctx.update_range(0, 0, 0, 9)
+    lat.close()
+
+
 def test_hot_start_biglattice_equals_single_lattice():
     """Hot start cut into slabs: halos come from the neighbours' streams through one exchange."""
     import qcdgpu_amd as q

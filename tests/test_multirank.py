@@ -52,6 +52,7 @@ def _single(cfg):
     (2, dict(group=3, L=[4, 4, 4, 4], beta=6.0, nhit=10, seed=54, ints=2, sweeps=2)),
     (3, dict(group=3, L=[8, 4, 4, 4], beta=5.5, nhit=3, seed=9, ints=1, sweeps=1, parts=[2, 4, 2])),
     (2, dict(group=3, L=[8, 4, 4, 4], beta=5.8, nhit=4, seed=21, ints=0, sweeps=1)),   # hot start
+    (2, dict(group=2, L=[16, 4, 4, 4], beta=2.3, nhit=5, seed=3, ints=1, sweeps=2)),   # boundary slices two deep
 ])
 def test_gloo_ranks_reproduce_single_process_run(world, cfg, tmp_path):
     got = _run(world, cfg, tmp_path)
