@@ -194,3 +194,106 @@ def init_to_args(init):
     return dict(group=init["GROUP"], L=L, beta=init["BETA"], nhit=init["NHIT"], ints=init["INTS"],
                 lux=lux, seed=init["RANDSERIES"], nav=init["NAV"], iter_=init["ITER"],
                 niter=init["NITER"])
+
+
+def gid_to_coords(L, gid):
+    """(x, y, z, t) of site gid = y + z*Ny + t*Ny*Nz + x*Ny*Nz*Nt."""
+    c = (C.c_int * 4)()
+    lib.qo_gid_to_coords(_L(L), gid, c)
+    return tuple(c[:])
+
+
+# ---------------------------------------------------------------------------------------------
+# O(N) scalar path (oracle/on_oracle.c)
+
+def _bind_on():
+    I, D, U, P = C.c_int, C.c_double, C.c_uint, C.c_void_p
+    pd = C.POINTER(C.c_double)
+    pi = C.POINTER(C.c_int)
+    lib.qon_create.restype = P
+    lib.qon_create.argtypes = [pi, I, I, I, D, D, D, D, D, I, U]
+    lib.qon_destroy.argtypes = [P]
+    lib.qon_init.argtypes = [P, I]
+    lib.qon_update_pass.argtypes = [P, I]
+    lib.qon_sweep.argtypes = [P]
+    lib.qon_measure_action.restype = D
+    lib.qon_measure_action.argtypes = [P]
+    lib.qon_measure_field.argtypes = [P, pd]
+    lib.qon_measure_correlators.argtypes = [P, pi, pd]
+    lib.qon_get.restype = D
+    lib.qon_get.argtypes = [P, I]
+    lib.qon_set.argtypes = [P, I, D]
+
+
+_bind_on()
+
+# defaults of the reference's O(N) main (O(N)/QCDGPU.cpp:121-128)
+ON_DEFAULTS = dict(skgroup=4, z=0.1561573990981998, lam=0.25, zeta=0.25, eta=0.1, b=9.661840260273483)
+
+
+class QonStruct(C.Structure):
+    _fields_ = [("L", C.c_int * 4), ("sites", C.c_int), ("precision", C.c_int), ("nhit", C.c_int),
+                ("skgroup", C.c_int), ("z", C.c_double), ("lam", C.c_double), ("zeta", C.c_double),
+                ("eta", C.c_double), ("b", C.c_double), ("sqrt_z_lambda_zeta", C.c_double),
+                ("max_U", C.c_double), ("field", C.c_void_p), ("nskip", C.c_int),
+                ("streams", C.c_void_p), ("rng_draws", C.c_ulonglong), ("acc", C.c_double * 2)]
+
+
+class OnLattice:
+    """The O(N) checker: field in site order gid = y + z*Ny + t*Ny*Nz + x*Ny*Nz*Nt."""
+
+    def __init__(self, L, precision=1, nhit=10, lux_level=3, randseries=7, **par):
+        p = dict(ON_DEFAULTS)
+        p.update(par)
+        self.L = tuple(L)
+        self.precision = precision
+        self.h = lib.qon_create(_L(L), precision, nhit, p["skgroup"], p["z"], p["lam"], p["zeta"],
+                                p["eta"], p["b"], lux_level, randseries)
+        self.s = C.cast(self.h, C.POINTER(QonStruct)).contents
+
+    def close(self):
+        if self.h:
+            lib.qon_destroy(self.h)
+            self.h = None
+
+    def init(self, hot=False):
+        lib.qon_init(self.h, int(hot))
+
+    def update_pass(self, parity):
+        lib.qon_update_pass(self.h, parity)
+
+    def sweep(self, n=1):
+        for _ in range(n):
+            lib.qon_sweep(self.h)
+
+    def action(self):
+        return lib.qon_measure_action(self.h)
+
+    def field_moments(self):
+        out = (C.c_double * 2)()
+        lib.qon_measure_field(self.h, out)
+        return np.array(out[:])
+
+    def correlators(self, step=(1, 1, 1, 1)):
+        out = (C.c_double * 2)()
+        lib.qon_measure_correlators(self.h, _L(step), out)
+        return np.array(out[:])
+
+    @property
+    def field(self):
+        dt = np.float64 if self.precision else np.float32
+        n = self.s.sites
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(self.s.field)
+        return np.frombuffer(buf, dtype=dt)
+
+    @property
+    def rng_draws(self):
+        return int(self.s.rng_draws)
+
+    @property
+    def acceptance(self):
+        return np.array(self.s.acc[:])
+
+    @property
+    def max_U(self):
+        return float(self.s.max_U)

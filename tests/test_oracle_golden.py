@@ -4,7 +4,9 @@ Bar: the reference prints 14 significant digits ("% 16.13e"); the restatement mu
 every printed digit, i.e. agree to 5e-14 relative (NaN where the reference gives NaN).
 """
 import ctypes as C
+import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -151,3 +153,66 @@ def test_parity_maps_partition_the_lattice():
     for gid in range(sites):
         for d in range(4):
             assert ol.lib.qo_neighbour_back(Lc, ol.lib.qo_neighbour(Lc, gid, d), d) == gid
+
+
+# ---------------------------------------------------------------------------------------------
+# O(N) scalar path: the checker's measurements against the reference's CPU re-measurement
+# (fixtures minted by oracle/make_golden_on.py from oracle/_ref/qcdgpu_on_check)
+
+ON_CASES = sorted(f for f in os.listdir(ol.GOLDEN_DIR) if f.startswith("on_") and f.endswith(".json"))
+
+
+@pytest.mark.parametrize("fname", ON_CASES)
+def test_on_measurements_match_reference(fname):
+    with open(os.path.join(ol.GOLDEN_DIR, fname)) as f:
+        doc = json.load(f)
+    p = doc["params"]
+    lat = ol.OnLattice(doc["L"], precision=1, **p)
+    lat.field[:] = np.array(doc["field"])
+    e = doc["expected"]
+    # the kernel's expression and the reference's CPU one differ in summation order only
+    assert lat.action() == pytest.approx(e["action"], rel=1e-12, abs=1e-12)
+    f1, f2 = lat.field_moments()
+    assert f1 == pytest.approx(e["field"], rel=1e-13)
+    assert f2 == pytest.approx(e["field2"], rel=1e-13)
+    c1, c2 = lat.correlators(doc["correlator_step"])
+    assert c1 == pytest.approx(e["correlator1"], rel=1e-13)
+    assert c2 == pytest.approx(e["correlator2"], rel=1e-13)
+    lat.close()
+
+
+def test_on_single_precision_tracks_double():
+    """The float build of the checker against its double build on the same field."""
+    a = ol.OnLattice((4, 4, 4, 6), precision=1)
+    b = ol.OnLattice((4, 4, 4, 6), precision=0)
+    a.init(hot=True)
+    b.init(hot=True)
+    assert np.allclose(a.field, b.field, rtol=2e-7)
+    assert b.action() == pytest.approx(a.action(), rel=2e-5)
+    assert np.allclose(b.field_moments(), a.field_moments(), rtol=2e-6)
+    a.close()
+    b.close()
+
+
+def test_on_update_properties():
+    """Metropolis pass: only sites of the pass's parity change, proposals stay inside [0, max_U),
+    the stream of every thread starts at a fresh batch, and the acceptance sums are consistent."""
+    L = (4, 4, 6, 4)
+    lat = ol.OnLattice(L, precision=1, nhit=5)
+    lat.init(hot=True)
+    before = np.array(lat.field)
+    d0 = lat.rng_draws
+    lat.update_pass(1)
+    after = np.array(lat.field)
+    changed = np.nonzero(before != after)[0]
+    assert len(changed) > 0
+    for gid in changed:
+        c = ol.gid_to_coords(L, int(gid))
+        assert sum(c) % 2 == 1
+    assert after.min() >= 0.0 and after.max() < lat.max_U
+    draws = lat.rng_draws - d0
+    half = lat.s.sites // 2
+    assert 4 * half <= draws <= 4 * 3 * half      # NHIT = 5: one to three quads per site
+    acc = lat.acceptance[1]
+    assert 0 <= acc <= 5 * half
+    lat.close()
