@@ -186,6 +186,61 @@ int qcd_prng_check(int device, unsigned rand_series, int lux_level, int streams,
  * x = k * 2^-24 in (0, 1), against the host libm in long double */
 int qcd_math_check(int device, int n, double max_ulp[4]);
 
+/* ---------------------------------------------------------------------------------------------
+ * O(N) scalar path: the reference's second model (its O(N) tree, MODEL_ON = 1), one real field
+ * value per site, checkerboard multi-hit Metropolis.  Same boundary as above: each entry point
+ * replaces the kernel_run call sites of O(N)/suncl/suncl.cpp cited beside it. */
+
+typedef struct qcd_on_ctx qcd_on_ctx;
+
+/* run_parameters of the O(N) model (O(N)/suncl/suncl.h:74-102; init keys SKGROUP, ON_Z, ON_LAMBDA,
+ * ON_ZETA, ON_ETA, ON_B, O(N)/suncl/suncl.cpp:273-286) */
+typedef struct {
+    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (Ny even) */
+    int      precision;    /* 0 = single, 1 = double (model_precision_single / _double) */
+    int      nhit;         /* NHIT: proposals per site and pass */
+    int      sk_group;     /* ON_SK_group: N of the O(N) group in the action */
+    double   z, lambda, zeta, eta, b;   /* ON_z, ON_lambda, ON_zeta, ON_eta, ON_b */
+    int      start_mode;   /* QCD_START_HOT or QCD_START_COLD */
+    int      lux_level;    /* RANLUX luxury level 0..4 */
+    unsigned rand_series;  /* RANDSERIES, non-zero */
+    int      device;
+} qcd_on_params;
+
+/* model::model_lattice_init + lattice_create_buffers (O(N)/suncl/suncl.cpp:1241-1445, 1926-2090);
+ * also derives ON_sqrt_z_lambda_zeta and ON_max_U (suncl.cpp:1244-1253) */
+int  qcd_on_create(qcd_on_ctx **out, const qcd_on_params *params);
+void qcd_on_destroy(qcd_on_ctx *ctx);
+
+/* lattice_simulate_start (suncl.cpp:2158-2176; kernels lattice_init_cold / lattice_init_hot,
+ * O(N)/oncl/oncl.cl:49-72): field = 0.25, or r * max_U; also resets the RANLUX streams */
+int qcd_on_init_lattice(qcd_on_ctx *ctx);
+
+/* kernel_run(sun_update_odd_X_id) / (sun_update_even_X_id) with the PRNG0->produce() in front of it
+ * (suncl.cpp:2233-2256; kernels update_odd / update_even, oncl.cl:74-366); parity 0 even, 1 odd */
+int qcd_on_update(qcd_on_ctx *ctx, int parity);
+/* n times lattice_update: odd pass, then even pass (suncl.cpp:2228-2232) */
+int qcd_on_sweep(qcd_on_ctx *ctx, int n);
+/* the same bracketed by HIP events: device time of the n sweeps in ms */
+int qcd_on_timed_sweeps(qcd_on_ctx *ctx, int n, double *elapsed_ms);
+
+/* lattice_measure_action, lattice_measure_plq, lattice_measure_corr with their reduce kernels
+ * (suncl.cpp:2177-2217; on_measurements_cl.cl:48-214), one pass over the field.  Per-site averages:
+ * out[0] action S, out[1] physical field, out[2] its square, out[3] correlator with the site at
+ * +step, out[4] correlator with the site at (+1,+1,+1,+1) */
+int qcd_on_measure(qcd_on_ctx *ctx, const int step[4], double out[5]);
+
+/* out[0]: random numbers consumed so far; out[1], out[2]: the acceptance sums of the last even and
+ * odd pass (ACC_RATE, oncl.cl:86-94, 216-218: sum over sites of NHIT minus the proposals rejected
+ * before the accepted one; the host divides by sites * NHIT, suncl.cpp:884) */
+int qcd_on_counters(qcd_on_ctx *ctx, unsigned long long out[3]);
+int qcd_on_max_u(const qcd_on_ctx *ctx, double *out);
+
+/* buffer_map of lattice_table (suncl.cpp:2107, 2152): the field in the reference's site order,
+ * element gid = y + z*Ny + t*Ny*Nz + x*Ny*Nz*Nt, float or double by precision */
+int qcd_on_upload(qcd_on_ctx *ctx, const void *host_field, size_t bytes);
+int qcd_on_download(qcd_on_ctx *ctx, void *host_field, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libqcdgpu_amd.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["kernels.h", "lattice.h", "ranlux.h", "su_math.h", "host_seed.h",
+# compiled apart, with contraction off on the device as well (see on_engine.hip)
+ON_SOURCE = "on_engine.hip"
+HEADERS = ["kernels.h", "lattice.h", "ranlux.h", "su_math.h", "host_seed.h", "fastmath.h", "on_kernels.h",
            os.path.join("..", "..", "include", "qcdgpu_amd.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
          "-Xarch_host", "-ffp-contract=off"]
@@ -38,7 +40,7 @@ def up_to_date():
     if not os.path.exists(LIB):
         return False
     t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in SOURCES + HEADERS)
+    return all(os.path.getmtime(os.path.join(CSRC, f)) <= t for f in SOURCES + [ON_SOURCE] + HEADERS)
 
 
 def build(force=False, verbose=False):
@@ -47,10 +49,20 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    libdir = os.path.dirname(LIB)
+    common = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+    objs, cmds = [], []
+    for src, extra in [(SOURCES[0], ["-Xarch_host", "-ffp-contract=off"]), (ON_SOURCE, ["-ffp-contract=off"])]:
+        obj = os.path.join(libdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        cmds.append([hipcc] + common + extra + ["-c", src, "-o", obj])
+    cmds.append([hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-o", LIB] + objs)
+    for c in cmds:
+        if verbose:
+            print(" ".join(c), file=sys.stderr)
+        subprocess.run(c, check=True, cwd=CSRC)
+    for obj in objs:
+        os.remove(obj)
     build_host(force, verbose)
     return LIB
 

@@ -27,6 +27,13 @@ class Params(C.Structure):
                 ("x0", C.c_int), ("nx_local", C.c_int), ("halo", C.c_int)]
 
 
+class OnParams(C.Structure):
+    _fields_ = [("L", C.c_int * 4), ("precision", C.c_int), ("nhit", C.c_int), ("sk_group", C.c_int),
+                ("z", C.c_double), ("lam", C.c_double), ("zeta", C.c_double), ("eta", C.c_double),
+                ("b", C.c_double), ("start_mode", C.c_int), ("lux_level", C.c_int),
+                ("rand_series", C.c_uint), ("device", C.c_int)]
+
+
 class Timing(C.Structure):
     _fields_ = [("update_launches", C.c_ulonglong), ("update_ms", C.c_double),
                 ("measure_launches", C.c_ulonglong), ("measure_ms", C.c_double),
@@ -43,7 +50,10 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
            "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
-           "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range"]
+           "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range",
+           "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
+           "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
+           "qcd_on_download"]
 
 
 def _load():
@@ -100,6 +110,18 @@ def _load():
     lib.qcd_rng_state_bytes.argtypes = [P]
     lib.qcd_rng_state_download.argtypes = [P, C.c_void_p, C.c_size_t]
     lib.qcd_rng_state_upload.argtypes = [P, C.c_void_p, C.c_size_t]
+    lib.qcd_on_create.argtypes = [C.POINTER(P), C.POINTER(OnParams)]
+    lib.qcd_on_destroy.argtypes = [P]
+    lib.qcd_on_destroy.restype = None
+    lib.qcd_on_init_lattice.argtypes = [P]
+    lib.qcd_on_update.argtypes = [P, I]
+    lib.qcd_on_sweep.argtypes = [P, I]
+    lib.qcd_on_timed_sweeps.argtypes = [P, I, pd]
+    lib.qcd_on_measure.argtypes = [P, C.POINTER(C.c_int), pd]
+    lib.qcd_on_counters.argtypes = [P, C.POINTER(C.c_ulonglong)]
+    lib.qcd_on_max_u.argtypes = [P, pd]
+    lib.qcd_on_upload.argtypes = [P, C.c_void_p, C.c_size_t]
+    lib.qcd_on_download.argtypes = [P, C.c_void_p, C.c_size_t]
     lib.qcd_host_gid_link.argtypes = [I, I, I, I, pd]
     lib.qcd_host_gid_randoms.argtypes = [I, I, I, C.POINTER(C.c_float)]
     return lib
@@ -287,3 +309,85 @@ def host_gid_randoms(gid, nhit, sites):
     r = (C.c_float * 6)()
     _check(lib.qcd_host_gid_randoms(gid, nhit, sites, r))
     return np.array(r[:], dtype=np.float32)
+
+
+# defaults of the reference's O(N) main (O(N)/QCDGPU.cpp:121-128)
+ON_DEFAULTS = dict(sk_group=4, z=0.1561573990981998, lam=0.25, zeta=0.25, eta=0.1, b=9.661840260273483)
+
+
+class OnContext:
+    """The O(N) scalar model on one device (qcd_on_ctx): one real field value per site,
+    checkerboard multi-hit Metropolis (the reference's O(N) tree)."""
+
+    def __init__(self, L, precision=0, nhit=10, start_mode=START_COLD, lux_level=3, rand_series=7,
+                 device=0, **par):
+        q = dict(ON_DEFAULTS)
+        q.update(par)
+        self.params = OnParams()
+        p = self.params
+        for i in range(4):
+            p.L[i] = L[i]
+        p.precision, p.nhit, p.sk_group = precision, nhit, q["sk_group"]
+        p.z, p.lam, p.zeta, p.eta, p.b = q["z"], q["lam"], q["zeta"], q["eta"], q["b"]
+        p.start_mode, p.lux_level, p.rand_series, p.device = start_mode, lux_level, rand_series, device
+        self.L = tuple(L)
+        self.sites = int(np.prod(L))
+        self.dtype = np.float64 if precision else np.float32
+        self.h = C.c_void_p()
+        _check(lib.qcd_on_create(C.byref(self.h), C.byref(p)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.qcd_on_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def init_lattice(self):
+        _check(lib.qcd_on_init_lattice(self.h))
+
+    def update(self, parity):
+        _check(lib.qcd_on_update(self.h, parity))
+
+    def sweep(self, n=1):
+        _check(lib.qcd_on_sweep(self.h, n))
+
+    def timed_sweeps(self, n):
+        ms = C.c_double()
+        _check(lib.qcd_on_timed_sweeps(self.h, n, C.byref(ms)))
+        return ms.value
+
+    def measure(self, step=(1, 1, 1, 1)):
+        """Per-site averages: action, field, field^2, correlator(+step), correlator(+1,+1,+1,+1)."""
+        out = (C.c_double * 5)()
+        _check(lib.qcd_on_measure(self.h, (C.c_int * 4)(*step), out))
+        return np.array(out[:])
+
+    def counters(self):
+        """(random numbers consumed, acceptance sum of the last even pass, of the last odd pass)."""
+        out = (C.c_ulonglong * 3)()
+        _check(lib.qcd_on_counters(self.h, out))
+        return tuple(int(v) for v in out)
+
+    @property
+    def max_U(self):
+        v = C.c_double()
+        _check(lib.qcd_on_max_u(self.h, C.byref(v)))
+        return v.value
+
+    def download(self):
+        a = np.empty(self.sites, dtype=self.dtype)
+        _check(lib.qcd_on_download(self.h, a.ctypes.data, a.nbytes))
+        return a
+
+    def upload(self, field):
+        a = np.ascontiguousarray(field, dtype=self.dtype)
+        assert a.size == self.sites
+        _check(lib.qcd_on_upload(self.h, a.ctypes.data, a.nbytes))

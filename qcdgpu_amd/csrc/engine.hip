@@ -55,6 +55,15 @@ inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
 
+// error text of the other translation units of the library (qcd_last_error returns it)
+namespace qcd {
+int fail_msg(int code, const char* msg)
+{
+    g_err = msg;
+    return code;
+}
+}  // namespace qcd
+
 struct qcd_ctx {
     qcd_params p;
     double2* edge_buf;        // message buffer of qcd_halo_copy (lazily allocated)

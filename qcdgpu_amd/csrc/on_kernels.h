@@ -1,0 +1,371 @@
+// on_kernels.h -- HIP kernels of the O(N) scalar path (gfx950): the checkerboard multi-hit Metropolis
+// update of the reference's "O(1) radial" model (O(N)/oncl/oncl.cl:74-366, action O(N)/oncl/o1cl.cl:41-144)
+// and its measurements (O(N)/oncl/on_measurements_cl.cl:48-214).
+//
+// One real number per site.  The reference keeps the field in site order; here it is split by
+// parity,  phi[parity][h],  h = gid >> 1  (gid = y + z*Ny + t*Ny*Nz + x*Ny*Nz*Nt), so that a pass
+// reads its own sites and all four forward neighbours as contiguous runs.  The pass is bound by
+// transcendentals (three fp64 logarithms, four fp32 ones, a square root and an exponential per
+// proposal), not by memory: 4-8 B of field per site against 200 B of generator state.
+//
+// Arithmetic types follow the kernel source text literally: its variables are hgpu_float (float
+// or double by PRECISION) and its literals are unsuffixed, i.e. double, so a single-precision
+// build evaluates most of the action in double and rounds where a value is stored into an
+// hgpu_float.  F below is hgpu_float.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "ranlux.h"
+
+namespace qcd {
+
+struct OnGeom {
+    int nx, ny, nz, nt;
+    int nyh;       // ny / 2
+    int slice_h;   // half-sites per x slice
+    int vh;        // half-sites of the lattice = threads of an update pass
+};
+
+// lattice_parameters[16..22] (O(N)/suncl/suncl.cpp:1987-1994) and SKGROUP
+template <typename F>
+struct OnPar {
+    F z, zeta, eta, b, sqrt_z_lambda_zeta, max_U;
+    int skgroup;
+};
+
+struct OnSite {
+    int x, y, z, t;
+};
+
+__device__ __forceinline__ OnSite on_site_of(const OnGeom& g, int h, int par)
+{
+    OnSite s;
+    const int yh = h % g.nyh;
+    int r = h / g.nyh;
+    s.z = r % g.nz;
+    r /= g.nz;
+    s.t = r % g.nt;
+    s.x = r / g.nt;
+    s.y = 2 * yh + ((par + s.x + s.z + s.t) & 1);
+    return s;
+}
+__device__ __forceinline__ int on_half_index(const OnGeom& g, int x, int y, int z, int t)
+{
+    return ((x * g.nt + t) * g.nz + z) * g.nyh + (y >> 1);
+}
+
+// half indices (in the opposite parity's array) of the four forward neighbours, periodic
+// (O(N)/kernel/neighbours.cl:123-148)
+__device__ __forceinline__ void on_forward(const OnGeom& g, const OnSite& s, int h, int nb[4])
+{
+    nb[0] = (s.x == g.nx - 1) ? h - (g.nx - 1) * g.slice_h : h + g.slice_h;
+    nb[1] = (s.y == g.ny - 1) ? h - (g.nyh - 1) : h + (s.y & 1);
+    nb[2] = (s.z == g.nz - 1) ? h - (g.nz - 1) * g.nyh : h + g.nyh;
+    nb[3] = (s.t == g.nt - 1) ? h - (g.nt - 1) * g.nyh * g.nz : h + g.nyh * g.nz;
+}
+
+__device__ __forceinline__ float on_log(float x) { return logf(x); }
+__device__ __forceinline__ double on_log(double x) { return log(x); }
+__device__ __forceinline__ float on_exp(float x) { return expf(x); }
+__device__ __forceinline__ double on_exp(double x) { return exp(x); }
+
+// o1cl.cl:41-45
+template <typename F>
+__device__ __forceinline__ F on_log_one_m(F Ux)
+{
+    return (F)log(1.0 - Ux);
+}
+// o1cl.cl:47-53
+template <typename F>
+__device__ __forceinline__ F on_phi(F l, F b, F eta)
+{
+    const F a = (F)((-1.0 + 0.5 * eta * l) * l);
+    return (F)(0.5 * a * a * b);
+}
+template <typename F>
+__device__ __forceinline__ F on_phi_of(F Ux, const OnPar<F>& p)
+{
+    return on_phi(on_log_one_m(Ux), p.b, p.eta);
+}
+
+// o1cl.cl:59-144 with forward differences (ON_SUB_SCHEME is commented out, O(N)/kernel/model.cl:60).
+// PhiN are the neighbours' Phi values: they do not depend on the proposal, so a site computes
+// them once for all its proposals (same inputs, same operations: same bits).
+template <typename F>
+__device__ __forceinline__ F on_action(F Ux, const F PhiN[4], const OnPar<F>& p)
+{
+    const F log_one_m_Ux = on_log_one_m(Ux);
+    const F Phi = on_phi(log_one_m_Ux, p.b, p.eta);
+    F term;
+    {
+        const F l0 = on_log(PhiN[0] / Phi);
+        term = l0 * l0;
+        const F l1 = on_log(PhiN[1] / Phi);
+        term += l1 * l1;
+        const F l2 = on_log(PhiN[2] / Phi);
+        term += l2 * l2;
+        const F l3 = p.zeta * on_log(PhiN[3] / Phi);
+        term += l3 * l3;
+    }
+    const double skgroupm1_2 = 0.5 * (p.skgroup - 1);
+    const double s2 = sqrt(2.0 * Phi);
+    const double m = (1.9999999999 < s2) ? 1.9999999999 : s2;
+    return (F)(-skgroupm1_2 * log(2.0 - m) - log((1.0 - p.eta * log_one_m_Ux) / (1.0 - Ux)) +
+               Phi * (Phi - 1.0 + p.sqrt_z_lambda_zeta * term) / p.z);
+}
+
+// o1cl.cl:146-154
+template <typename F>
+__device__ __forceinline__ F on_physical(F Ux, const OnPar<F>& p)
+{
+    return (F)sqrt(2.0 * on_phi_of(Ux, p));
+}
+
+// A thread's RANLUX stream with ONE delivered batch in LDS (column `tid` of a [24][BLOCK] float
+// array), refilled on demand.  Same consumption rule as the link update's streams: a pass starts
+// at a fresh batch.  Ten proposals need 20 numbers, so a refill only happens for NHIT > 12.
+template <int BLOCK, int NSKIP>
+struct RlxOne {
+    float* buf;
+    RlxHome h;
+    int pos, nb, cur;   // the state in front of batch k is in slot cur ^ (k & 1), k = nb
+
+    __device__ __forceinline__ void skip(RlxRegs& r) const
+    {
+        if (NSKIP > 0) rlx_skip_static<(NSKIP > 0 ? NSKIP : 24)>(r);
+        else rlx_skip(r, h.q, h.rem);
+    }
+    __device__ __forceinline__ void deliver()
+    {
+        RlxRegs r;
+        h.load_state(r, cur ^ (nb & 1));
+        rlx_batch(r, buf, BLOCK);
+        skip(r);
+        nb++;
+        h.store_state(r, cur ^ (nb & 1));
+        pos = 0;
+    }
+    __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
+    {
+        h.bind(view, stream);
+        buf = lds_column;
+        cur = (int)(*h.ctl & 1u);
+        nb = 0;
+        deliver();
+    }
+    __device__ __forceinline__ void draw4(float r[4])
+    {
+        if (pos == 24) deliver();
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = buf[(pos + k) * BLOCK];
+        pos += 4;
+    }
+    // the stream resumes in front of the batch after the last one delivered
+    __device__ __forceinline__ void close() { *h.ctl = (unsigned)(cur ^ (nb & 1)); }
+};
+
+template <int BLOCK>
+__device__ __forceinline__ unsigned long long on_wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// update_even / update_odd (oncl.cl:74-219, 221-366): up to NHIT proposals U' = r * max_U, two per
+// quad of random numbers, the first with r' < exp(S_old - S_new) is stored.
+// counters[0]: random numbers consumed (4 per quad); counters[1 + parity]: the ACC_RATE sum of
+// this pass, sum over sites of NHIT minus the proposals rejected before the accepted one.
+template <typename F, int BLOCK, int NSKIP>
+__global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const OnGeom g, const int parity,
+                                                     const OnPar<F> p, const int nhit, const RlxView rv,
+                                                     unsigned long long* __restrict__ counters)
+{
+    __shared__ float rbuf[24 * BLOCK];
+    const int h = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long quads = 0, acc = 0;
+    if (h < g.vh) {
+        F* __restrict__ own = phi + (size_t)parity * g.vh;
+        const F* __restrict__ other = phi + (size_t)(parity ^ 1) * g.vh;
+        const OnSite s = on_site_of(g, h, parity);
+        int nb[4];
+        on_forward(g, s, h, nb);
+        const F Ux = own[h];
+        F PhiN[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) PhiN[k] = other[nb[k]];
+        RlxOne<BLOCK, NSKIP> rs;
+        rs.open(rv, h, rbuf + threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(PhiN[k], p);
+        const F action_old = on_action(Ux, PhiN, p);
+
+        int out = nhit;
+        bool flag = false;
+        F Unew = Ux;
+        const int nhit_2 = nhit >> 1;
+        for (int i = 0; i < nhit_2 && !flag; i++) {
+            float rnd[4];
+            rs.draw4(rnd);
+            quads++;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!flag) {
+                    const F cand = (F)rnd[2 * k] * p.max_U;
+                    const F action_new = on_action(cand, PhiN, p);
+                    const F deltaS = on_exp(action_old - action_new);
+                    if ((F)rnd[2 * k + 1] < deltaS) {
+                        Unew = cand;
+                        flag = true;
+                    } else {
+                        out--;
+                    }
+                }
+            }
+        }
+        if ((nhit & 1) && !flag) {
+            float rnd[4];
+            rs.draw4(rnd);
+            quads++;
+            const F cand = (F)rnd[0] * p.max_U;
+            const F action_new = on_action(cand, PhiN, p);
+            const F deltaS = on_exp(action_old - action_new);
+            if ((F)rnd[1] < deltaS) {
+                Unew = cand;
+                flag = true;
+            } else {
+                out--;
+            }
+        }
+        if (flag) own[h] = Unew;
+        rs.close();
+        acc = (unsigned long long)out;
+    }
+    quads = on_wave_sum<BLOCK>(quads);
+    acc = on_wave_sum<BLOCK>(acc);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counters[0], 4ull * quads);
+        atomicAdd(&counters[1 + parity], acc);
+    }
+}
+
+// lattice_init_cold / lattice_init_hot (oncl.cl:49-72, o1_update_cl.cl:48-60): cold = 0.25; hot =
+// r * max_U with the first number of a quad -- the thread of site pair (2h, 2h+1) takes a fresh
+// batch and gives the first numbers of its quads 0 and 1 to the two sites
+template <typename F, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_on_init(F* __restrict__ phi, const OnGeom g, const int hot, const F max_U,
+                                                   const RlxView rv, unsigned long long* __restrict__ counters)
+{
+    __shared__ float rbuf[24 * BLOCK];
+    const int h = blockIdx.x * BLOCK + threadIdx.x;
+    if (h >= g.vh) return;
+    F v0 = (F)0.25, v1 = (F)0.25;
+    if (hot) {
+        RlxOne<BLOCK, 0> rs;
+        rs.open(rv, h, rbuf + threadIdx.x);
+        float a[4], b[4];
+        rs.draw4(a);
+        rs.draw4(b);
+        rs.close();
+        v0 = (F)a[0] * max_U;
+        v1 = (F)b[0] * max_U;
+        atomicAdd(&counters[0], 8ull);
+    }
+    // site 2h has parity (x + z + t) & 1 (its y is even), site 2h + 1 the other one
+    const OnSite s = on_site_of(g, h, 0);
+    const int par0 = (s.x + s.z + s.t) & 1;
+    phi[(size_t)par0 * g.vh + h] = v0;
+    phi[(size_t)(par0 ^ 1) * g.vh + h] = v1;
+}
+
+// lattice_measurement, lattice_measurement_plq, lattice_measurement_correlator
+// (on_measurements_cl.cl:48-107, 122-154, 167-214) in one pass: per site the action S, the
+// physical field, its square, and the field's products with the sites at +step and at
+// (+1,+1,+1,+1); fp64 sums, one partial of 5 doubles per workgroup.
+template <typename F, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_on_measure(const F* __restrict__ phi, const OnGeom g, const OnPar<F> p,
+                                                      const int4 step, double* __restrict__ partial)
+{
+    __shared__ double red[5][BLOCK / 64];
+    const int w = blockIdx.x * BLOCK + threadIdx.x;
+    double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (w < 2 * g.vh) {
+        const int par = w / g.vh;
+        const int h = w - par * g.vh;
+        const F* __restrict__ own = phi + (size_t)par * g.vh;
+        const F* __restrict__ other = phi + (size_t)(par ^ 1) * g.vh;
+        const OnSite s = on_site_of(g, h, par);
+        int nb[4];
+        on_forward(g, s, h, nb);
+        const F Ux = own[h];
+        F PhiN[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(other[nb[k]], p);
+        v[0] = (double)on_action(Ux, PhiN, p);
+        const F f = on_physical(Ux, p);
+        v[1] = (double)f;
+        v[2] = (double)(F)(f * f);
+        // kernel/neighbours.cl:200-213: one conditional subtraction per direction
+        int c2[4] = {s.x + step.x, s.y + step.y, s.z + step.z, s.t + step.w};
+        int c3[4] = {s.x + 1, s.y + 1, s.z + 1, s.t + 1};
+        const int ext[4] = {g.nx, g.ny, g.nz, g.nt};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            if (c2[d] >= ext[d]) c2[d] -= ext[d];
+            if (c3[d] >= ext[d]) c3[d] = 0;
+        }
+        const int p2 = (c2[0] + c2[1] + c2[2] + c2[3]) & 1, p3 = (c3[0] + c3[1] + c3[2] + c3[3]) & 1;
+        const F u2 = phi[(size_t)p2 * g.vh + on_half_index(g, c2[0], c2[1], c2[2], c2[3])];
+        const F u3 = phi[(size_t)p3 * g.vh + on_half_index(g, c3[0], c3[1], c3[2], c3[3])];
+        v[3] = (double)(F)(f * on_physical(u2, p));
+        v[4] = (double)(F)(f * on_physical(u3, p));
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double sum = 0.0;
+        for (int wv = 0; wv < BLOCK / 64; wv++) sum += red[threadIdx.x][wv];
+        partial[(size_t)blockIdx.x * 5 + threadIdx.x] = sum;
+    }
+}
+
+// adds the workgroup partials in index order (one workgroup; deterministic)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_on_reduce(const double* __restrict__ partial, const int n, double* __restrict__ out)
+{
+    __shared__ double red[BLOCK];
+    for (int k = 0; k < 5; k++) {
+        double sum = 0.0;
+        for (int i = threadIdx.x; i < n; i += BLOCK) sum += partial[(size_t)i * 5 + k];
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int off = BLOCK / 2; off > 0; off >>= 1) {
+            if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[k] = red[0];
+        __syncthreads();
+    }
+}
+
+// field in site order (the reference's lattice_table, o1_matrix_memory.cl:41-54) <-> phi[parity][h]
+template <typename F, bool TO_ENGINE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_on_convert(F* __restrict__ phi, const OnGeom g, F* __restrict__ table)
+{
+    const int gid = blockIdx.x * BLOCK + threadIdx.x;
+    if (gid >= 2 * g.vh) return;
+    const int h = gid >> 1;
+    const OnSite s = on_site_of(g, h, 0);
+    const int par = ((s.x + s.z + s.t) & 1) ^ (gid & 1);
+    if (TO_ENGINE) phi[(size_t)par * g.vh + h] = table[gid];
+    else table[gid] = phi[(size_t)par * g.vh + h];
+}
+
+}  // namespace qcd
