@@ -20,20 +20,30 @@ HOST_BIN = os.path.join(HERE, "bin", "qcdgpu")
 HOST_SOURCES = ["model.cpp", "qcdgpu_main.cpp"]
 
 
-def build_host(force=False, verbose=False):
-    """The C++ host shell (run API + program entry) above the C-ABI."""
-    srcs = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES]
-    deps = srcs + [os.path.join(HOST_DIR, "model.h"), LIB]
-    if (not force and os.path.exists(HOST_BIN)
-            and all(os.path.getmtime(d) <= os.path.getmtime(HOST_BIN) for d in deps)):
-        return HOST_BIN
-    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall"] + srcs + ["-o", HOST_BIN, "-L" + os.path.dirname(LIB),
+ON_BIN = os.path.join(HERE, "bin", "qcdgpu_on")
+ON_HOST_SOURCES = ["on_model.cpp", "qcdgpu_on_main.cpp", "model.cpp"]
+
+
+def _build_program(target, sources, headers, force, verbose):
+    srcs = [os.path.join(HOST_DIR, f) for f in sources]
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in headers] + [LIB]
+    if (not force and os.path.exists(target)
+            and all(os.path.getmtime(d) <= os.path.getmtime(target) for d in deps)):
+        return target
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall"] + srcs + ["-o", target, "-L" + os.path.dirname(LIB),
            "-lqcdgpu_amd", "-Wl,-rpath,$ORIGIN/../lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return HOST_BIN
+    return target
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host shells (run API + program entry) above the C-ABI: the SU(N) program and the
+    O(N) one (the reference builds them from two source trees)."""
+    _build_program(ON_BIN, ON_HOST_SOURCES, ["model.h", "on_model.h"], force, verbose)
+    return _build_program(HOST_BIN, HOST_SOURCES, ["model.h"], force, verbose)
 
 
 def up_to_date():

@@ -179,3 +179,51 @@ def test_full_size_single_precision_properties():
     assert 4 * 2 * sites <= cnt[0] <= 4 * 5 * 2 * sites
     assert 0 < cnt[1] <= 10 * sites // 2 and 0 < cnt[2] <= 10 * sites // 2
     assert np.isfinite(m).all() and m[0] != s0
+
+
+QCDGPU_ON = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qcdgpu_amd", "bin", "qcdgpu_on")
+
+
+def test_host_program_reproduces_checker_run(tmp_path):
+    """qcdgpu_on (init file -> run -> result file) in double precision against the same run of the
+    checker: every column of the result table."""
+    import re
+    import subprocess
+    L, nav, it, niter, nhit = (6, 4, 6, 4), 2, 4, 2, 10
+    with open(tmp_path / "init.dat", "w") as f:
+        f.write("\tL1 = 6\n\tL2 = 4\n\tL3 = 6\n\tL4 = 4\n\tNAV = %d\n\tITER = %d\n\tNITER = %d\n\tNHIT = %d\n" % (nav, it, niter, nhit))
+        f.write("\tINTS = 0\n\tPRNG = RANLUX3\n\tRANDSERIES = 21\n\tPRECISION = 2\n\tOUTPUTPATH = %s/\n" % tmp_path)
+    r = subprocess.run([QCDGPU_ON, str(tmp_path / "init.dat"), "-ON_ETA=0.2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    text = open(re.search(r"result file: (\S+)", r.stdout).group(1)).read()
+    assert " eta                         : 2.0000000000000e-01" in text
+    rows = np.array([[float(x) for x in ln.split()[1:]] for ln in text.splitlines() if re.match(r"^\s+\d+\s+[- ]\d\.\d+e", ln)])
+    assert rows.shape == (it, 11)
+
+    lat = ol.OnLattice(L, precision=1, nhit=nhit, randseries=21, eta=0.2)
+    lat.init(hot=True)
+    step = (4, 4, 4, 4)
+    sites = lat.s.sites
+
+    def sample(updated):
+        f1, f2 = lat.field_moments()
+        c1, c2 = lat.correlators(step)
+        s = lat.action()
+        are = lat.acceptance[0] / (sites * nhit * niter) if updated else 0.0
+        aro = lat.acceptance[1] / (sites * nhit * niter) if updated else 0.0
+        return [f1, f2, f2 - f1 * f1, s, 0.0, s, c1 - f1 * f1, c2 - f1 * f1, are, aro, 0.5 * (are + aro)]
+
+    want = [sample(False)]
+    lat.sweep(nav)
+    for _ in range(it - 1):
+        lat.sweep(niter)
+        want.append(sample(True))
+    want = np.array(want)
+    assert np.allclose(rows, want, rtol=1e-11, atol=1e-12), np.max(np.abs(rows - want))
+    lat.close()
+
+
+def test_host_program_rejects_what_it_does_not_run(tmp_path):
+    import subprocess
+    r = subprocess.run([QCDGPU_ON, "-GROUP=3"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "GROUP = 1" in r.stderr
