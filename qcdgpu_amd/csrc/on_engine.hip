@@ -60,6 +60,7 @@ struct qcd_on_ctx {
     size_t elem;                   // sizeof(F)
     RlxView rv;
     unsigned long long* counters;  // [0] numbers drawn, [1] ACC_RATE sum of the last even pass, [2] odd
+    unsigned long long* wg_counts; // per workgroup of an update pass: numbers drawn, ACC_RATE part
     double* partial;
     int npartial;
     double* result_dev;
@@ -99,7 +100,11 @@ int seed_streams(qcd_on_ctx* c)
     const int ns = c->g.vh;
     const int nskip = rlx_nskip_for_level(c->p.lux_level);
     const std::vector<int> seeds = stream_seeds(c->p.rand_series, 0, ns);
-    std::vector<unsigned> st((size_t)RLX_STATE_WORDS * ns);
+    const int ns_pad = cdiv(ns, ON_RLX_TILE) * ON_RLX_TILE;
+    std::vector<unsigned> st((size_t)RLX_STATE_WORDS * ns_pad);
+    auto at = [](int w, int i) {   // [tile][word][lane], see RlxTileHome
+        return ((size_t)(i / ON_RLX_TILE) * RLX_STATE_WORDS + w) * ON_RLX_TILE + i % ON_RLX_TILE;
+    };
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
     if (nthreads > 16) nthreads = 16;
@@ -108,8 +113,8 @@ int seed_streams(qcd_on_ctx* c)
         for (int i = lo; i < hi; i++) {
             RlxRegs r;
             rlx_seed_state(seeds[(size_t)i], nskip, r);
-            for (int w = 0; w < 24; w++) st[(size_t)w * ns + i] = r.s[w];
-            st[(size_t)24 * ns + i] = r.c;
+            for (int w = 0; w < 24; w++) st[at(w, i)] = r.s[w];
+            st[at(24, i)] = r.c;
         }
     };
     std::vector<std::thread> pool;
@@ -133,13 +138,14 @@ template <typename F>
 int launch_update(qcd_on_ctx* c, int parity)
 {
     const dim3 grid(cdiv(c->g.vh, ON_BLOCK)), block(ON_BLOCK);
-    HIP_TRY(hipMemsetAsync(c->counters + 1 + parity, 0, sizeof(unsigned long long), c->stream));
     if (c->p.lux_level == 3)
         hipLaunchKernelGGL((k_on_update<F, ON_BLOCK, 223>), grid, block, 0, c->stream, (F*)c->phi, c->g, parity,
-                           params_of<F>(c), c->p.nhit, c->rv, c->counters);
+                           params_of<F>(c), c->p.nhit, c->rv, c->wg_counts);
     else
         hipLaunchKernelGGL((k_on_update<F, ON_BLOCK, 0>), grid, block, 0, c->stream, (F*)c->phi, c->g, parity,
-                           params_of<F>(c), c->p.nhit, c->rv, c->counters);
+                           params_of<F>(c), c->p.nhit, c->rv, c->wg_counts);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_on_count<1024>), dim3(1), dim3(1024), 0, c->stream, c->wg_counts, (int)grid.x, parity, c->counters);
     HIP_TRY(hipGetLastError());
     return QCD_OK;
 }
@@ -250,12 +256,13 @@ int qcd_on_create(qcd_on_ctx** out, const qcd_on_params* p)
     tryhip(hipEventCreate(&c->ev0), "hipEventCreate");
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
     tryhip(hipMalloc(&c->phi, (size_t)2 * g.vh * c->elem), "hipMalloc(field)");
-    const size_t stw = (size_t)RLX_STATE_WORDS * g.vh * sizeof(unsigned);
-    tryhip(hipMalloc(&c->rv.slot0, 2 * stw), "hipMalloc(ranlux)");
-    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_STATE_WORDS * g.vh : nullptr;
+    const size_t st_words = (size_t)RLX_STATE_WORDS * cdiv(g.vh, ON_RLX_TILE) * ON_RLX_TILE;
+    tryhip(hipMalloc(&c->rv.slot0, 2 * st_words * sizeof(unsigned)), "hipMalloc(ranlux)");
+    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + st_words : nullptr;
     tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
     c->rv.ns = g.vh;
     tryhip(hipMalloc(&c->counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)");
+    tryhip(hipMalloc(&c->wg_counts, (size_t)2 * cdiv(g.vh, ON_BLOCK) * sizeof(unsigned long long)), "hipMalloc(workgroup counters)");
     tryhip(hipMalloc(&c->partial, (size_t)5 * c->npartial * sizeof(double)), "hipMalloc(partials)");
     tryhip(hipMalloc(&c->result_dev, 8 * sizeof(double)), "hipMalloc(result)");
     tryhip(hipHostMalloc(&c->result_host, 8 * sizeof(double)), "hipHostMalloc(result)");
@@ -276,6 +283,7 @@ void qcd_on_destroy(qcd_on_ctx* c)
     (void)hipFree(c->rv.slot0);
     (void)hipFree(c->rv.ctl);
     (void)hipFree(c->counters);
+    (void)hipFree(c->wg_counts);
     (void)hipFree(c->partial);
     (void)hipFree(c->result_dev);
     if (c->result_host) (void)hipHostFree(c->result_host);
@@ -294,10 +302,14 @@ int qcd_on_init_lattice(qcd_on_ctx* c)
     const dim3 grid(cdiv(c->g.vh, ON_BLOCK)), block(ON_BLOCK);
     const int hot = c->p.start_mode == QCD_START_HOT;
     if (c->p.precision)
-        hipLaunchKernelGGL((k_on_init<double, ON_BLOCK>), grid, block, 0, c->stream, (double*)c->phi, c->g, hot, (double)c->max_U, c->rv, c->counters);
+        hipLaunchKernelGGL((k_on_init<double, ON_BLOCK>), grid, block, 0, c->stream, (double*)c->phi, c->g, hot, (double)c->max_U, c->rv);
     else
-        hipLaunchKernelGGL((k_on_init<float, ON_BLOCK>), grid, block, 0, c->stream, (float*)c->phi, c->g, hot, (float)c->max_U, c->rv, c->counters);
+        hipLaunchKernelGGL((k_on_init<float, ON_BLOCK>), grid, block, 0, c->stream, (float*)c->phi, c->g, hot, (float)c->max_U, c->rv);
     HIP_TRY(hipGetLastError());
+    if (hot) {   // two quads per thread
+        const unsigned long long drawn = 8ull * (unsigned long long)c->g.vh;
+        HIP_TRY(hipMemcpyAsync(c->counters, &drawn, sizeof(drawn), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->initialized = true;
     return QCD_OK;

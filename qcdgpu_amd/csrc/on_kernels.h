@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "fastmath.h"
 #include "kernels.h"
 #include "ranlux.h"
 
@@ -71,11 +72,16 @@ __device__ __forceinline__ double on_log(double x) { return log(x); }
 __device__ __forceinline__ float on_exp(float x) { return expf(x); }
 __device__ __forceinline__ double on_exp(double x) { return exp(x); }
 
+// The fp64 logarithms, the square root and the two fp64 quotients of the action come from a Math
+// policy (fastmath.h): the update pass uses the table logarithm and the hardware-seeded reciprocal
+// and square root (errors of 1e-16 in an action of order one, the size of the difference between
+// any two libms), the measurements use the device libm.
+
 // o1cl.cl:41-45
-template <typename F>
-__device__ __forceinline__ F on_log_one_m(F Ux)
+template <typename F, class Math>
+__device__ __forceinline__ F on_log_one_m(F Ux, const Math& m)
 {
-    return (F)log(1.0 - Ux);
+    return (F)m.log_of(1.0 - Ux);
 }
 // o1cl.cl:47-53
 template <typename F>
@@ -84,19 +90,19 @@ __device__ __forceinline__ F on_phi(F l, F b, F eta)
     const F a = (F)((-1.0 + 0.5 * eta * l) * l);
     return (F)(0.5 * a * a * b);
 }
-template <typename F>
-__device__ __forceinline__ F on_phi_of(F Ux, const OnPar<F>& p)
+template <typename F, class Math>
+__device__ __forceinline__ F on_phi_of(F Ux, const OnPar<F>& p, const Math& m)
 {
-    return on_phi(on_log_one_m(Ux), p.b, p.eta);
+    return on_phi(on_log_one_m(Ux, m), p.b, p.eta);
 }
 
 // o1cl.cl:59-144 with forward differences (ON_SUB_SCHEME is commented out, O(N)/kernel/model.cl:60).
 // PhiN are the neighbours' Phi values: they do not depend on the proposal, so a site computes
 // them once for all its proposals (same inputs, same operations: same bits).
-template <typename F>
-__device__ __forceinline__ F on_action(F Ux, const F PhiN[4], const OnPar<F>& p)
+template <typename F, class Math>
+__device__ __forceinline__ F on_action(F Ux, const F PhiN[4], const OnPar<F>& p, const Math& m)
 {
-    const F log_one_m_Ux = on_log_one_m(Ux);
+    const F log_one_m_Ux = on_log_one_m(Ux, m);
     const F Phi = on_phi(log_one_m_Ux, p.b, p.eta);
     F term;
     {
@@ -110,26 +116,64 @@ __device__ __forceinline__ F on_action(F Ux, const F PhiN[4], const OnPar<F>& p)
         term += l3 * l3;
     }
     const double skgroupm1_2 = 0.5 * (p.skgroup - 1);
-    const double s2 = sqrt(2.0 * Phi);
-    const double m = (1.9999999999 < s2) ? 1.9999999999 : s2;
-    return (F)(-skgroupm1_2 * log(2.0 - m) - log((1.0 - p.eta * log_one_m_Ux) / (1.0 - Ux)) +
-               Phi * (Phi - 1.0 + p.sqrt_z_lambda_zeta * term) / p.z);
+    const double s2 = m.sqrt_of(2.0 * Phi);
+    const double mn = (1.9999999999 < s2) ? 1.9999999999 : s2;
+    return (F)(-skgroupm1_2 * m.log_of(2.0 - mn) - m.log_of(m.div(1.0 - p.eta * log_one_m_Ux, 1.0 - Ux)) +
+               m.div(Phi * (Phi - 1.0 + p.sqrt_z_lambda_zeta * term), p.z));
 }
 
 // o1cl.cl:146-154
-template <typename F>
-__device__ __forceinline__ F on_physical(F Ux, const OnPar<F>& p)
+template <typename F, class Math>
+__device__ __forceinline__ F on_physical(F Ux, const OnPar<F>& p, const Math& m)
 {
-    return (F)sqrt(2.0 * on_phi_of(Ux, p));
+    return (F)m.sqrt_of(2.0 * on_phi_of(Ux, p, m));
 }
 
 // A thread's RANLUX stream with ONE delivered batch in LDS (column `tid` of a [24][BLOCK] float
 // array), refilled on demand.  Same consumption rule as the link update's streams: a pass starts
 // at a fresh batch.  Ten proposals need 20 numbers, so a refill only happens for NHIT > 12.
+// Generator state of the O(N) streams: tiles of ON_RLX_TILE streams, a tile's 25 words stored
+// one after the other ([tile][word][lane]), so that a workgroup's state is one contiguous 25 KiB
+// run per slot.  (Word-major over ALL streams, the link update's layout, puts the 25 words of a
+// stream 4*ns bytes apart -- 33 MB at 64^4 -- and every one of a wave's 50 state accesses on a
+// page of its own.)
+constexpr int ON_RLX_TILE = 256;
+
+struct RlxTileHome {
+    unsigned* __restrict__ s0;   // this stream's lane in word 0 of its tile, slot 0
+    unsigned* __restrict__ ctl;
+    size_t slot_stride;          // words from slot 0 to slot 1
+    int q, rem;
+
+    __device__ __forceinline__ void bind(const RlxView& view, int stream)
+    {
+        const int tile = stream / ON_RLX_TILE;
+        s0 = view.slot0 + (size_t)tile * ON_RLX_TILE * RLX_STATE_WORDS + (stream - tile * ON_RLX_TILE);
+        ctl = view.ctl + stream;
+        slot_stride = (size_t)(view.slot1 - view.slot0);
+        q = view.q;
+        rem = view.rem;
+    }
+    __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
+    {
+        const unsigned* __restrict__ p = s0 + (size_t)slot * slot_stride;
+#pragma unroll
+        for (int w = 0; w < 24; w++) r.s[w] = p[w * ON_RLX_TILE];
+        r.c = p[24 * ON_RLX_TILE];
+    }
+    __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
+    {
+        unsigned* __restrict__ p = s0 + (size_t)slot * slot_stride;
+#pragma unroll
+        for (int w = 0; w < 24; w++) p[w * ON_RLX_TILE] = r.s[w];
+        p[24 * ON_RLX_TILE] = r.c;
+    }
+};
+
 template <int BLOCK, int NSKIP>
 struct RlxOne {
     float* buf;
-    RlxHome h;
+    RlxTileHome h;
     int pos, nb, cur;   // the state in front of batch k is in slot cur ^ (k & 1), k = nb
 
     __device__ __forceinline__ void skip(RlxRegs& r) const
@@ -176,14 +220,19 @@ __device__ __forceinline__ unsigned long long on_wave_sum(unsigned long long v)
 
 // update_even / update_odd (oncl.cl:74-219, 221-366): up to NHIT proposals U' = r * max_U, two per
 // quad of random numbers, the first with r' < exp(S_old - S_new) is stored.
-// counters[0]: random numbers consumed (4 per quad); counters[1 + parity]: the ACC_RATE sum of
-// this pass, sum over sites of NHIT minus the proposals rejected before the accepted one.
+// wg_counts[2b], [2b+1]: workgroup b's random numbers consumed (4 per quad) and its part of the
+// ACC_RATE sum of this pass, sum over sites of NHIT minus the proposals rejected before the accepted one.
 template <typename F, int BLOCK, int NSKIP>
 __global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const OnGeom g, const int parity,
                                                      const OnPar<F> p, const int nhit, const RlxView rv,
-                                                     unsigned long long* __restrict__ counters)
+                                                     unsigned long long* __restrict__ wg_counts)
 {
     __shared__ float rbuf[24 * BLOCK];
+    __shared__ double2 logtab[LOG_TABLE_ENTRIES];
+    MathFast::fill<BLOCK>(logtab);
+    __syncthreads();
+    MathFast fm;
+    fm.tab = logtab;
     const int h = blockIdx.x * BLOCK + threadIdx.x;
     unsigned long long quads = 0, acc = 0;
     if (h < g.vh) {
@@ -199,8 +248,8 @@ __global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const 
         RlxOne<BLOCK, NSKIP> rs;
         rs.open(rv, h, rbuf + threadIdx.x);
 #pragma unroll
-        for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(PhiN[k], p);
-        const F action_old = on_action(Ux, PhiN, p);
+        for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(PhiN[k], p, fm);
+        const F action_old = on_action(Ux, PhiN, p, fm);
 
         int out = nhit;
         bool flag = false;
@@ -214,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const 
             for (int k = 0; k < 2; k++) {
                 if (!flag) {
                     const F cand = (F)rnd[2 * k] * p.max_U;
-                    const F action_new = on_action(cand, PhiN, p);
+                    const F action_new = on_action(cand, PhiN, p, fm);
                     const F deltaS = on_exp(action_old - action_new);
                     if ((F)rnd[2 * k + 1] < deltaS) {
                         Unew = cand;
@@ -230,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const 
             rs.draw4(rnd);
             quads++;
             const F cand = (F)rnd[0] * p.max_U;
-            const F action_new = on_action(cand, PhiN, p);
+            const F action_new = on_action(cand, PhiN, p, fm);
             const F deltaS = on_exp(action_old - action_new);
             if ((F)rnd[1] < deltaS) {
                 Unew = cand;
@@ -243,11 +292,47 @@ __global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const 
         rs.close();
         acc = (unsigned long long)out;
     }
+    // one pair of sums per workgroup, added up by k_on_count (131072 waves adding to one address
+    // with atomics take longer than the whole update)
+    __shared__ unsigned long long wsum[2][BLOCK / 64];
     quads = on_wave_sum<BLOCK>(quads);
     acc = on_wave_sum<BLOCK>(acc);
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&counters[0], 4ull * quads);
-        atomicAdd(&counters[1 + parity], acc);
+        wsum[0][threadIdx.x >> 6] = quads;
+        wsum[1][threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned long long t = 0;
+        for (int w = 0; w < BLOCK / 64; w++) t += wsum[threadIdx.x][w];
+        wg_counts[2 * (size_t)blockIdx.x + threadIdx.x] = threadIdx.x == 0 ? 4ull * t : t;
+    }
+}
+
+// sums the per-workgroup pairs of an update pass: counters[0] += numbers drawn, counters[1 + parity] = acceptance sum
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_on_count(const unsigned long long* __restrict__ wg_counts, const int n, const int parity,
+                                                    unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long red[2][BLOCK];
+    unsigned long long a = 0, b = 0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        a += wg_counts[2 * (size_t)i];
+        b += wg_counts[2 * (size_t)i + 1];
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counters[0] += red[0][0];
+        counters[1 + parity] = red[1][0];
     }
 }
 
@@ -256,7 +341,7 @@ __global__ __launch_bounds__(BLOCK) void k_on_update(F* __restrict__ phi, const 
 // batch and gives the first numbers of its quads 0 and 1 to the two sites
 template <typename F, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_on_init(F* __restrict__ phi, const OnGeom g, const int hot, const F max_U,
-                                                   const RlxView rv, unsigned long long* __restrict__ counters)
+                                                   const RlxView rv)
 {
     __shared__ float rbuf[24 * BLOCK];
     const int h = blockIdx.x * BLOCK + threadIdx.x;
@@ -271,7 +356,6 @@ __global__ __launch_bounds__(BLOCK) void k_on_init(F* __restrict__ phi, const On
         rs.close();
         v0 = (F)a[0] * max_U;
         v1 = (F)b[0] * max_U;
-        atomicAdd(&counters[0], 8ull);
     }
     // site 2h has parity (x + z + t) & 1 (its y is even), site 2h + 1 the other one
     const OnSite s = on_site_of(g, h, 0);
@@ -301,10 +385,11 @@ __global__ __launch_bounds__(BLOCK) void k_on_measure(const F* __restrict__ phi,
         on_forward(g, s, h, nb);
         const F Ux = own[h];
         F PhiN[4];
+        const MathLib lm;
 #pragma unroll
-        for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(other[nb[k]], p);
-        v[0] = (double)on_action(Ux, PhiN, p);
-        const F f = on_physical(Ux, p);
+        for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(other[nb[k]], p, lm);
+        v[0] = (double)on_action(Ux, PhiN, p, lm);
+        const F f = on_physical(Ux, p, lm);
         v[1] = (double)f;
         v[2] = (double)(F)(f * f);
         // kernel/neighbours.cl:200-213: one conditional subtraction per direction
@@ -319,8 +404,8 @@ __global__ __launch_bounds__(BLOCK) void k_on_measure(const F* __restrict__ phi,
         const int p2 = (c2[0] + c2[1] + c2[2] + c2[3]) & 1, p3 = (c3[0] + c3[1] + c3[2] + c3[3]) & 1;
         const F u2 = phi[(size_t)p2 * g.vh + on_half_index(g, c2[0], c2[1], c2[2], c2[3])];
         const F u3 = phi[(size_t)p3 * g.vh + on_half_index(g, c3[0], c3[1], c3[2], c3[3])];
-        v[3] = (double)(F)(f * on_physical(u2, p));
-        v[4] = (double)(F)(f * on_physical(u3, p));
+        v[3] = (double)(F)(f * on_physical(u2, p, lm));
+        v[4] = (double)(F)(f * on_physical(u3, p, lm));
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) {
