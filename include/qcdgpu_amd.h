@@ -120,6 +120,15 @@ int qcd_measure_polyakov(qcd_ctx *ctx, double out[4]);
 int qcd_measure_plaquette_sums(qcd_ctx *ctx, double sums[2]);
 int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
 
+/* kernel_run(sun_action_diff_{x,y,z}_id) / kernel_run(sun_polyakov_diff_{x,y,z}_id) with their reduce
+ * kernels (suncl.cpp:5432-5449, 5458-5476; kernels lattice_action_diff_*, sun_measurements_cl.cl:186-616,
+ * lattice_polyakov_diff_*, polyakov.cl:142-402): profiles along a space axis (0 x, 1 y, 2 z).
+ * sums[2*i], sums[2*i+1] = raw (spat, temp) ReTr plaquette sums resp. (Re P, Im P) sums over the
+ * owned sites with coordinate i along the axis; i runs over nx_local (axis 0), Ny or Nz values.
+ * The host turns them into S_s/S_t resp. PL/PL_im per plane (suncl.cpp:1116-1260). */
+int qcd_measure_plaquette_profile_sums(qcd_ctx *ctx, int axis, double *sums);
+int qcd_measure_polyakov_profile_sums(qcd_ctx *ctx, int axis, double *sums);
+
 /* kernel_run(sun_measurement_wilson_id) + sun_wilson_loop_reduce_id (suncl.cpp:5266-5275): the
  * R x T Wilson loop averaged over sites and the three space-time planes (denominator 3V,
  * suncl.cpp:1606-1611).  One context owning the whole lattice only. */

@@ -959,6 +959,64 @@ static void polyakov_sums_range(const qo_lattice *lat, int x_begin, int x_end, d
     out[3] = p4;
 }
 
+/* Profiles along a space axis (kernels lattice_action_diff_{x,y,z}, SU(N)/suncl/sun_measurements_cl.cl:186-616,
+ * and lattice_polyakov_diff_{x,y,z}, SU(N)/suncl/polyakov.cl:142-402): the per-site plaquette sums
+ * and Polyakov loops binned by the site's coordinate along `axis` (0 = x, 1 = y, 2 = z).
+ * out[2*i], out[2*i+1] = (spat, temp) ReTr sums resp. (Re, Im) loop sums of plane i.  The reference
+ * has these on its device path only: "parity unpinned". */
+void qo_plaquette_profile_sums(const qo_lattice *lat, int axis, double *out)
+{
+    for (int i = 0; i < 2 * lat->L[axis]; i++) out[i] = 0.0;
+    for (int gid = 0; gid < lat->sites; gid++) {
+        int c[4];
+        double s, t;
+        qo_gid_to_coords(lat->L, (unsigned)gid, c);
+        plaquette_sums_range(lat, gid, gid + 1, &s, &t);
+        out[2 * c[axis]] += s;
+        out[2 * c[axis] + 1] += t;
+    }
+}
+
+void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out)
+{
+    const int *L = lat->L;
+    const int slice = L[1] * L[2] * L[3];
+    for (int i = 0; i < 2 * L[axis]; i++) out[i] = 0.0;
+    /* one spatial site at a time through the range routine: a copy of the lattice's x-slice
+     * structure is not needed, the routine only reads */
+    for (int x1 = 0; x1 < L[0]; x1++)
+        for (int x2 = 0; x2 < L[1]; x2++)
+            for (int x3 = 0; x3 < L[2]; x3++) {
+                int c[4] = { x1, x2, x3, 0 };
+                double tr_re = 0.0, tr_im = 0.0;
+                if (lat->group == 3) {
+                    const qo_su3 *tab = (const qo_su3 *)lat->links;
+                    qo_su3 m2 = tab[qo_coords_to_gid(L, c) * lat->nd + 3];
+                    for (int x4 = 1; x4 < L[3]; x4++) {
+                        c[3] = x4;
+                        qo_su3 m3 = qo_mul3(&m2, &tab[qo_coords_to_gid(L, c) * lat->nd + 3]);
+                        m2 = m3;
+                    }
+                    tr_re = m2.u1.re + m2.v2.re + m2.w3.re;
+                    tr_im = m2.u1.im + m2.v2.im + m2.w3.im;
+                } else {
+                    const qo_su2 *tab = (const qo_su2 *)lat->links;
+                    qo_su2 m2 = tab[qo_coords_to_gid(L, c) * lat->nd + 3];
+                    for (int x4 = 1; x4 < L[3]; x4++) {
+                        c[3] = x4;
+                        qo_su2 m3 = qo_mul2(&m2, &tab[qo_coords_to_gid(L, c) * lat->nd + 3]);
+                        m2 = m3;
+                    }
+                    tr_re = m2.u1.re + m2.v2.re;
+                    tr_im = m2.u1.im + m2.v2.im;
+                }
+                const int b = axis == 0 ? x1 : (axis == 1 ? x2 : x3);
+                out[2 * b] += tr_re;
+                out[2 * b + 1] += tr_im;
+            }
+    (void)slice;
+}
+
 void qo_estimates(const double *data, int n, double *mean_out, double *var_out)
 {
     /* lattice_estimates, analysis_cpp.cpp:81-93 -- sample 0 excluded, biased variance */

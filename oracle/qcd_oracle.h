@@ -123,6 +123,12 @@ double qo_wilson_loop(const qo_lattice *lat, int R, int T);
 /* out = Re P, Im P, |P|^2, |P|^4 averages; "parity unpinned" */
 void qo_polyakov(const qo_lattice *lat, double out[4]);
 
+/* profiles along a space axis (0 x, 1 y, 2 z): out[2*i], out[2*i+1] = (spat, temp) plaquette sums
+ * resp. (Re, Im) Polyakov-loop sums of the sites with coordinate i; device path of the reference
+ * only: "parity unpinned" */
+void qo_plaquette_profile_sums(const qo_lattice *lat, int axis, double *out);
+void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out);
+
 /* statistics, SU(N)/suncpp/Measurements/analysis_cpp.cpp:81-93 */
 void qo_estimates(const double *data, int n, double *mean, double *variance);
 

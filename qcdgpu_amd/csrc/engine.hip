@@ -78,6 +78,8 @@ struct qcd_ctx {
     float* gidr;
     double2* partial;
     int npartial;
+    long partial_len;         // double2 elements allocated for partial
+    int result_len;           // doubles in result_dev / result_host
     double* result_dev;
     double* result_host;  // pinned
     unsigned long long* draws_dev;
@@ -487,9 +489,13 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     c->rv.ns = g.vh_int;
     if (p->start_mode == QCD_START_GID)
         tryhip(hipMalloc(&c->gidr, (size_t)6 * g.nx * g.gslice * sizeof(float)), "hipMalloc(gid table)");
-    tryhip(hipMalloc(&c->partial, (size_t)2 * c->npartial * sizeof(double2)), "hipMalloc(partials)");
-    tryhip(hipMalloc(&c->result_dev, 8 * sizeof(double)), "hipMalloc(result)");
-    tryhip(hipHostMalloc(&c->result_host, 8 * sizeof(double)), "hipHostMalloc(result)");
+    // the profile measurements need one pair per plane and up to 64 partials per plane
+    const int max_ext = g.nx > g.ny ? (g.nx > g.nz ? g.nx : g.nz) : (g.ny > g.nz ? g.ny : g.nz);
+    c->partial_len = 2L * c->npartial > 64L * max_ext ? 2L * c->npartial : 64L * max_ext;
+    c->result_len = 2 * max_ext > 8 ? 2 * max_ext : 8;
+    tryhip(hipMalloc(&c->partial, (size_t)c->partial_len * sizeof(double2)), "hipMalloc(partials)");
+    tryhip(hipMalloc(&c->result_dev, c->result_len * sizeof(double)), "hipMalloc(result)");
+    tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double)), "hipHostMalloc(result)");
     tryhip(hipMalloc(&c->draws_dev, sizeof(unsigned long long)), "hipMalloc(draws)");
     tryhip(hipMalloc(&c->redo_list, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list)");
     tryhip(hipMalloc(&c->redo_count, 2 * sizeof(unsigned)), "hipMalloc(redo count)");
@@ -721,6 +727,39 @@ int qcd_measure_wilson(qcd_ctx* c, int R, int T, double* out)
     *out = s[0] / (3.0 * (double)c->g.gsites);   // SU(N)/suncl/suncl.cpp:1606-1611
     return QCD_OK;
 }
+
+// shared driver of the two profile measurements
+static int measure_profile(qcd_ctx* c, int axis, double* sums, bool polyakov)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (axis < 0 || axis > 2) return fail(QCD_ERR_INVALID, "axis %d is not 0 (x), 1 (y) or 2 (z)", axis);
+    if (!sums) return fail(QCD_ERR_INVALID, "null output");
+    const Geom& g = c->g;
+    const int ext = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+    const long sites = polyakov ? (long)g.nx * g.ny * g.nz : (long)g.nx * g.gslice;
+    const int plane = (int)(sites / ext);
+    int chunks = cdiv(plane, MEAS_BLOCK);
+    if (chunks > 64) chunks = 64;
+    if ((long)ext * chunks > c->partial_len || 2 * ext > c->result_len)
+        return fail(QCD_ERR_UNSUPPORTED, "profile of %d planes does not fit the reduction buffers", ext);
+    Timed tm(c, 1);
+    const dim3 grid(ext * chunks), block(MEAS_BLOCK);
+    if (c->p.group == 3) {
+        if (polyakov) hipLaunchKernelGGL((k_polyakov_profile<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
+        else hipLaunchKernelGGL((k_plaquette_profile<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
+    } else {
+        if (polyakov) hipLaunchKernelGGL((k_polyakov_profile<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
+        else hipLaunchKernelGGL((k_plaquette_profile<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
+    }
+    HIP_TRY(hipGetLastError());
+    rc = reduce_partials(c, chunks, ext, sums);
+    if (rc) return rc;
+    return tm.finish();
+}
+
+int qcd_measure_plaquette_profile_sums(qcd_ctx* c, int axis, double* sums) { return measure_profile(c, axis, sums, false); }
+int qcd_measure_polyakov_profile_sums(qcd_ctx* c, int axis, double* sums) { return measure_profile(c, axis, sums, true); }
 
 int qcd_measure_polyakov_sums(qcd_ctx* c, double sums[4])
 {

@@ -164,6 +164,7 @@ void model::lattice_get_init_file(char* file)
         if (!strcmp(v, "GETWILSON")) get_wilson_loop = true;
         if (!strcmp(v, "GETRETRACE")) get_plaquettes_avr = true;
         if (!strcmp(v, "PL_LEVEL")) PL_level = p.iVarVal;
+        if (!strcmp(v, "GETSDIFF")) get_actions_diff = true;
         if (!strcmp(v, "WILSONR")) wilson_R = p.iVarVal;
         if (!strcmp(v, "WILSONT")) wilson_T = p.iVarVal;
     }
@@ -348,6 +349,90 @@ void model::measure(int index)
     for (int i = 0; i < 4; i++) pl_raw_[i][index] = pl[i];
     if (get_wilson_loop) check(qcd_measure_wilson(SubLat[0].ctx, wilson_R, wilson_T, &wl_[index]), "qcd_measure_wilson");
     derive_sample(index);
+    if (get_actions_diff || PL_level > 2) measure_profiles(index);
+}
+
+// S(x), S(y), S(z) and the Polyakov loop plane by plane (lattice_analysis_Action_diff,
+// lattice_analysis_PL_diff, SU(N)/suncl/suncl.cpp:1116-1260).  A plane of constant x lies in one part;
+// planes of constant y or z are cut by the parts, whose sums are added before normalising with the
+// full plane (for parts of equal width this is the reference's average over parts).
+void model::measure_profiles(int index)
+{
+    const double g = lattice_group;
+    for (int axis = 0; axis < 3; axis++) {
+        const int ext = lattice_full_size[axis];
+        std::vector<double> plq(2 * ext, 0.0), pl(2 * ext, 0.0), buf;
+        int x0 = 0;
+        for (auto& s : SubLat) {
+            const int n = axis == 0 ? s.Nx : ext;
+            const int at = axis == 0 ? x0 : 0;
+            buf.assign(2 * n, 0.0);
+            if (get_actions_diff) {
+                check(qcd_measure_plaquette_profile_sums(s.ctx, axis, buf.data()), "qcd_measure_plaquette_profile_sums");
+                for (int i = 0; i < 2 * n; i++) plq[2 * at + i] += buf[i];
+            }
+            if (PL_level > 2) {
+                check(qcd_measure_polyakov_profile_sums(s.ctx, axis, buf.data()), "qcd_measure_polyakov_profile_sums");
+                for (int i = 0; i < 2 * n; i++) pl[2 * at + i] += buf[i];
+            }
+            x0 += s.Nx;
+        }
+        const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3] / ext;
+        const double n2 = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] / ext;
+        for (int b = 0; b < ext; b++) {
+            if (get_actions_diff) {
+                const double ss = BETA * (1 - plq[2 * b] / (3 * v) / g), st = BETA * (1 - plq[2 * b + 1] / (3 * v) / g);
+                s_diff_[axis][(size_t)b * ITER + index] = 0.5 * (ss + st);   // S_total_diff
+            }
+            if (PL_level > 2) {
+                pl_diff_[axis][(size_t)b * ITER + index] = pl[2 * b] / (n2 * g);
+                pl_diff_im_[axis][(size_t)b * ITER + index] = pl[2 * b + 1] / (n2 * g);
+            }
+        }
+    }
+}
+
+// the two "Differentiated ..." sections of the result file (SU(N)/suncl/suncl.cpp:1696-1790)
+void model::write_profiles(FILE* stream)
+{
+    static const char* axis_name[3] = {"X", "Y", "Z"};
+    auto row = [&](const char* label, const std::vector<double>& series, int ext, bool variance) {
+        fprintf(stream, "\n%s", label);
+        for (int b = 0; b < ext; b++) {
+            data_analysis d;
+            d.data.assign(series.begin() + (size_t)b * ITER, series.begin() + (size_t)(b + 1) * ITER);
+            lattice_data_analysis(&d);
+            fprintf(stream, "% 16.13e ", variance ? d.variance : d.mean_value);
+        }
+    };
+    if (PL_level > 2) {
+        fprintf(stream, " ***************************************************\n");
+        fprintf(stream, "Differentiated Polyakov loop data (#, PL, PL_im, PL_variance, PL_im_variance):");
+        fprintf(stream, "\n");
+        for (int axis = 0; axis < 3; axis++) {
+            const int ext = lattice_full_size[axis];
+            fprintf(stream, "\n%s              ", axis_name[axis]);
+            for (int i = 0; i < ext; i++) fprintf(stream, "%2u                   ", i);
+            row("PL             ", pl_diff_[axis], ext, false);
+            row("PL_im          ", pl_diff_im_[axis], ext, false);
+            row("PL_variance    ", pl_diff_[axis], ext, true);
+            row("PL_im_variance ", pl_diff_im_[axis], ext, true);
+            fprintf(stream, "\n");
+        }
+    }
+    if (get_actions_diff) {
+        fprintf(stream, " ***************************************************\n");
+        fprintf(stream, "Differentiated S data (#, S_total, S_variance):");
+        fprintf(stream, "\n");
+        for (int axis = 0; axis < 3; axis++) {
+            const int ext = lattice_full_size[axis];
+            fprintf(stream, "\n%s              ", axis_name[axis]);
+            for (int i = 0; i < ext; i++) fprintf(stream, "%2u                   ", i);
+            row("S             ", s_diff_[axis], ext, false);
+            row("S_variance    ", s_diff_[axis], ext, true);
+            fprintf(stream, "\n");
+        }
+    }
 }
 
 // the sample's table entries from its raw lattice sums
@@ -588,6 +673,16 @@ void model::lattice_save_state(void)
     fwrite(&n64, sizeof(n64), 1, stream);
     fwrite(pl_raw_[2].data(), sizeof(double), (size_t)ITER, stream);
     fwrite(pl_raw_[3].data(), sizeof(double), (size_t)ITER, stream);
+    // the plane-resolved series: per axis the lengths and the values of S_total_diff, PL_diff, PL_im_diff
+    const char magic3[8] = {'Q', 'C', 'D', 'P', 'R', 'F', '1', 0};
+    fwrite(magic3, 1, 8, stream);
+    fwrite(&n64, sizeof(n64), 1, stream);
+    for (int a = 0; a < 3; a++)
+        for (const std::vector<double>* v : {&s_diff_[a], &pl_diff_[a], &pl_diff_im_[a]}) {
+            const unsigned long long len = v->size();
+            fwrite(&len, sizeof(len), 1, stream);
+            fwrite(v->data(), sizeof(double), v->size(), stream);
+        }
     if (fclose(stream)) printf("The file was not closed!\n");
     time(&last_save_);
 }
@@ -692,7 +787,24 @@ void model::lattice_load_state(void)
             fread(pl_raw_[3].data(), sizeof(double), (size_t)ITER, stream) != (size_t)ITER)
             printf("state file: |P|^2, |P|^4 sums are truncated\n");
     }
+    bool profiles_read = false;
+    if (fread(magic2, 1, 8, stream) == 8 && !memcmp(magic2, "QCDPRF1", 8) && fread(&n64, sizeof(n64), 1, stream) == 1 &&
+        n64 == (unsigned long long)ITER) {
+        profiles_read = true;
+        for (int a = 0; a < 3 && profiles_read; a++)
+            for (std::vector<double>* v : {&s_diff_[a], &pl_diff_[a], &pl_diff_im_[a]}) {
+                unsigned long long len = 0;
+                if (fread(&len, sizeof(len), 1, stream) != 1) { profiles_read = false; break; }
+                std::vector<double> tmp((size_t)len);
+                if (fread(tmp.data(), sizeof(double), tmp.size(), stream) != tmp.size()) { profiles_read = false; break; }
+                if (v->empty()) continue;                       // series not asked for in this run
+                if (tmp.size() != v->size()) { profiles_read = false; break; }   // asked for, but not in the file
+                *v = tmp;
+            }
+    }
     fclose(stream);
+    if (!profiles_read && (get_actions_diff || PL_level > 2))
+        throw model_error("state file does not carry the plane-resolved series this run asks for (GETSDIFF / PL_LEVEL = 3)");
     for (int i = 0; i < ITER_counter && i < ITER; i++) derive_sample(i);
     // halo slices of the parts
     for (int dir = 0; dir < 4; dir++)
@@ -714,7 +826,11 @@ void model::lattice_simulate(void)
     for (int i = 0; i < 2; i++) plq_raw_[i].assign(ITER, 0.0);
     for (int i = 0; i < 4; i++) pl_raw_[i].assign(ITER, 0.0);
     wl_.assign(ITER, 0.0);
-
+    for (int a = 0; a < 3; a++) {
+        s_diff_[a].assign(get_actions_diff ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);
+        pl_diff_[a].assign(PL_level > 2 ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);
+        pl_diff_im_[a].assign(PL_level > 2 ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);
+    }
     free(timestart);
     timestart = current_datetime(&ltimestart);
     time(&last_save_);
@@ -826,6 +942,7 @@ void model::lattice_write_results(void)
     FILE* stream = fopen(result_file.c_str(), "w+");
     if (!stream) throw model_error("cannot write " + result_file);
     fputs(header.c_str(), stream);
+    write_profiles(stream);
     fprintf(stream, " ***************************************************\n");
     fprintf(stream, " Data fields:\n");
     fprintf(stream, "    #,  ");

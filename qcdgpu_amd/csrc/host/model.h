@@ -15,6 +15,7 @@
 //     layer (SU(N)/clinterface/clinterface.cpp:225-284); main() turns it into exit status 1.
 #pragma once
 
+#include <cstdio>
 #include <ctime>
 #include <stdexcept>
 #include <string>
@@ -121,6 +122,7 @@ public:
     bool get_actions_avr = true;
     bool get_plaquettes_avr = true;
     bool get_wilson_loop = false;  // GETWILSON: the wilson_R x wilson_T loop as a further column
+    bool get_actions_diff = false; // S(x), S(y), S(z): the action plane by plane (suncl.h:144; init key GETSDIFF is an addition)
     bool profiling = false;        // GPU_debug.profiling
     // lattice state files (SU(N)/suncl/suncl.h:80,154-175; defaults of main, QCDGPU.cpp:203,215)
     bool turnoff_config_save = true;                 // do not write configurations
@@ -171,6 +173,10 @@ public:
 private:
     std::vector<double> plq_[3], act_[3], pl_[4];
     std::vector<double> wl_;
+    // plane-resolved series, [axis][plane * ITER + sample]: S_total_diff and (PL, PL_im) diff
+    std::vector<double> s_diff_[3], pl_diff_[3], pl_diff_im_[3];
+    void measure_profiles(int index);
+    void write_profiles(FILE* stream);
     std::vector<double> plq_raw_[2], pl_raw_[4];   // per sample: the lattice sums the table entries derive from
     void derive_sample(int index);
     std::string device_names_;

@@ -31,7 +31,7 @@ int main(int argc, char** argv)
         model0->NHITPar = 1;
         model0->BETA = 6.5;
         model0->ints = model::model_start_cold;
-        model0->PL_level = 2;
+        model0->PL_level = 3;   // SU(N)/QCDGPU.cpp:191: loops, moments and the plane-resolved loops
 
         const char* init = nullptr;
         bool parse_only = false;

@@ -1150,6 +1150,73 @@ __global__ __launch_bounds__(BLOCK) void k_polyakov(const double2* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Profiles along a space axis (kernels lattice_action_diff_{x,y,z}, SU(N)/suncl/sun_measurements_cl.cl:186-616,
+// and lattice_polyakov_diff_{x,y,z}, SU(N)/suncl/polyakov.cl:142-402): the plaquette sums and the
+// Polyakov loops of the sites with coordinate b along `axis` (0 = x, 1 = y, 2 = z).  Workgroup
+// (b, c) = blockIdx.x / chunks, blockIdx.x % chunks sums every chunks-th stretch of BLOCK sites of
+// plane b; k_reduce adds the chunks of a plane in index order.  Rarely run: written for
+// clarity, not for coalescing.
+
+// site number j of the plane: the coordinates other than `axis` run y, z, (t,) x from fastest to slowest
+__device__ __forceinline__ Site plane_site(const Geom& g, int axis, int b, int j, bool with_t)
+{
+    int c[4];   // xs, y, z, t
+    const int ext[4] = {g.nx, g.ny, g.nz, with_t ? g.nt : 1};
+    const int order[4] = {1, 2, 3, 0};
+    c[3] = 0;
+    for (int k = 0; k < 4; k++) {
+        const int d = order[k];
+        if (d == axis) continue;
+        c[d] = j % ext[d];
+        j /= ext[d];
+    }
+    c[axis] = b;
+    Site s;
+    s.xs = c[0]; s.y = c[1]; s.z = c[2]; s.t = c[3];
+    return s;
+}
+
+template <int GROUP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_plaquette_profile(const double2* __restrict__ U, const Geom g, const int axis,
+                                                             const int chunks, const int plane_sites,
+                                                             double2* __restrict__ partial)
+{
+    const int b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
+    double spat = 0.0, temp = 0.0;
+    for (int j = c * BLOCK + threadIdx.x; j < plane_sites; j += chunks * BLOCK) {
+        const Site x = plane_site(g, axis, b, j, true);
+        spat += retr_plaquette<GROUP>(U, g, x, 0, 1);
+        spat += retr_plaquette<GROUP>(U, g, x, 0, 2);
+        spat += retr_plaquette<GROUP>(U, g, x, 1, 2);
+        temp += retr_plaquette<GROUP>(U, g, x, 0, 3);
+        temp += retr_plaquette<GROUP>(U, g, x, 1, 3);
+        temp += retr_plaquette<GROUP>(U, g, x, 2, 3);
+    }
+    block_reduce_store<BLOCK>(spat, temp, partial);
+}
+
+template <int GROUP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_polyakov_profile(const double2* __restrict__ U, const Geom g, const int axis,
+                                                            const int chunks, const int plane_sites,
+                                                            double2* __restrict__ partial)
+{
+    const int b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
+    double re = 0.0, im = 0.0;
+    for (int j = c * BLOCK + threadIdx.x; j < plane_sites; j += chunks * BLOCK) {
+        Site x = plane_site(g, axis, b, j, false);
+        mat<GROUP> m = load_site_link<GROUP>(U, g, 3, x);
+        for (int tt = 1; tt < g.nt; tt++) {
+            x.t = tt;
+            m = mul(m, load_site_link<GROUP>(U, g, 3, x));
+        }
+        const cplx tr = trace(m);
+        re += tr.re;
+        im += tr.im;
+    }
+    block_reduce_store<BLOCK>(re, im, partial);
+}
+
+// ---------------------------------------------------------------------------------------------
 // stand-alone re-unitarisation of every owned link (kernel lattice_GramSchmidt, suncl.cl:349-396)
 
 template <int GROUP, int BLOCK>

@@ -5,8 +5,9 @@
 // One real number per site.  The reference keeps the field in site order; here it is split by
 // parity,  phi[parity][h],  h = gid >> 1  (gid = y + z*Ny + t*Ny*Nz + x*Ny*Nz*Nt), so that a pass
 // reads its own sites and all four forward neighbours as contiguous runs.  The pass is bound by
-// transcendentals (three fp64 logarithms, four fp32 ones, a square root and an exponential per
-// proposal), not by memory: 4-8 B of field per site against 200 B of generator state.
+// arithmetic (three fp64 logarithms, four fp32 ones, a square root and an exponential per proposal,
+// 250 RANLUX steps per site), and what memory traffic there is, is generator state: 200 B per site
+// against 4-8 B of field.
 //
 // Arithmetic types follow the kernel source text literally: its variables are hgpu_float (float
 // or double by PRECISION) and its literals are unsuffixed, i.e. double, so a single-precision
@@ -129,9 +130,6 @@ __device__ __forceinline__ F on_physical(F Ux, const OnPar<F>& p, const Math& m)
     return (F)m.sqrt_of(2.0 * on_phi_of(Ux, p, m));
 }
 
-// A thread's RANLUX stream with ONE delivered batch in LDS (column `tid` of a [24][BLOCK] float
-// array), refilled on demand.  Same consumption rule as the link update's streams: a pass starts
-// at a fresh batch.  Ten proposals need 20 numbers, so a refill only happens for NHIT > 12.
 // Generator state of the O(N) streams: tiles of ON_RLX_TILE streams, a tile's 25 words stored
 // one after the other ([tile][word][lane]), so that a workgroup's state is one contiguous 25 KiB
 // run per slot.  (Word-major over ALL streams, the link update's layout, puts the 25 words of a
@@ -170,6 +168,9 @@ struct RlxTileHome {
     }
 };
 
+// A thread's RANLUX stream with ONE delivered batch in LDS (column `tid` of a [24][BLOCK] float
+// array), refilled on demand.  Same consumption rule as the link update's streams: a pass starts
+// at a fresh batch.  Ten proposals need 20 numbers, so a refill only happens for NHIT > 12.
 template <int BLOCK, int NSKIP>
 struct RlxOne {
     float* buf;

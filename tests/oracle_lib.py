@@ -36,6 +36,8 @@ def _load():
     lib.qo_plaquette.argtypes = [P, pd]
     lib.qo_action.argtypes = [P, pd]
     lib.qo_polyakov.argtypes = [P, pd]
+    lib.qo_plaquette_profile_sums.argtypes = [P, I, pd]
+    lib.qo_polyakov_profile_sums.argtypes = [P, I, pd]
     lib.qo_simulate.argtypes = [P, I, I, I, pd, pd]
     lib.qo_estimates.argtypes = [pd, I, pd, pd]
     lib.qo_export_device_layout.argtypes = [P, pd, I]
@@ -127,6 +129,16 @@ class Lattice:
         out = (C.c_double * 4)()
         lib.qo_polyakov(self.h, out)
         return np.array(out[:])
+
+    def plaquette_profile_sums(self, axis):
+        out = (C.c_double * (2 * self.L[axis]))()
+        lib.qo_plaquette_profile_sums(self.h, axis, out)
+        return np.array(out[:]).reshape(self.L[axis], 2)
+
+    def polyakov_profile_sums(self, axis):
+        out = (C.c_double * (2 * self.L[axis]))()
+        lib.qo_polyakov_profile_sums(self.h, axis, out)
+        return np.array(out[:]).reshape(self.L[axis], 2)
 
     def rows(self):
         return 12 if self.group == 3 else 4

@@ -261,3 +261,73 @@ def test_gid_biglattice_matches_reference_vector():
         rows.append(np.concatenate([big.plaquette(), big.action()]))
     want = np.array(fx["samples"], dtype=float)
     assert np.max(np.abs(np.array(rows) - want) / np.abs(want)) < 1e-12
+
+
+def _profile_rows(text, title):
+    """{axis: {label: values}} of one "Differentiated ..." section of a result file."""
+    sec = text[text.index(title):]
+    sec = sec[:sec.index(" ***************************************************", 10)]
+    out, axis = {}, None
+    for line in sec.splitlines()[1:]:
+        parts = line.split()
+        if not parts:
+            continue
+        if parts[0] in ("X", "Y", "Z"):
+            axis = parts[0]
+            out[axis] = {}
+        elif axis:
+            out[axis][parts[0]] = np.array([float(v) for v in parts[1:]])
+    return out
+
+
+def test_cli_plane_resolved_observables(tmp_path):
+    """PL_LEVEL = 3 and GETSDIFF: the two "Differentiated ..." sections of the result file, on the
+    uncut lattice and cut into parts, against the checker's plane sums."""
+    L = (8, 4, 6, 4)
+    keys = dict(GROUP=3, ND=4, L1=L[0], L2=L[1], L3=L[2], L4=L[3], BETA=5.9, NHIT=10, INTS=1, PRNG="RANLUX3",
+                RANDSERIES=54, NAV=0, ITER=3, NITER=1, PL_LEVEL=3)
+    text, _, rows, _ = _run(tmp_path / "a", keys, "\tGETSDIFF = 1\n")
+    text2, _, rows2, _ = _run(tmp_path / "b", keys, "\tGETSDIFF = 1\n\tN1 = {2, 6}\n\tDEVICE = {0, 0}\n")
+    pl = _profile_rows(text, "Differentiated Polyakov loop data")
+    sd = _profile_rows(text, "Differentiated S data")
+    pl2 = _profile_rows(text2, "Differentiated Polyakov loop data")
+    sd2 = _profile_rows(text2, "Differentiated S data")
+    lat = ol.Lattice(3, L, 5.9, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE)
+    want_s = {a: [] for a in range(3)}
+    want_p = {a: [] for a in range(3)}
+    for _ in range(2):
+        lat.sweep(1)
+        for a in range(3):
+            plane = np.prod(L) // L[a]
+            p = lat.plaquette_profile_sums(a) / (3.0 * plane)
+            want_s[a].append(0.5 * (5.9 * (1 - p[:, 0] / 3) + 5.9 * (1 - p[:, 1] / 3)))
+            want_p[a].append(lat.polyakov_profile_sums(a) / (plane / L[3] * 3.0))
+    for a, name in enumerate("XYZ"):
+        assert len(sd[name]["S"]) == L[a]
+        assert np.allclose(sd[name]["S"], np.mean(want_s[a], axis=0), rtol=1e-11)
+        assert np.allclose(sd[name]["S_variance"], np.var(want_s[a], axis=0), rtol=1e-6, atol=1e-18)
+        wp = np.mean(want_p[a], axis=0)
+        assert np.allclose(pl[name]["PL"], wp[:, 0], rtol=1e-9, atol=1e-13)
+        assert np.allclose(pl[name]["PL_im"], wp[:, 1], rtol=1e-9, atol=1e-13)
+        for key in sd[name]:
+            assert np.allclose(sd[name][key], sd2[name][key], rtol=1e-11, atol=1e-18)
+        for key in pl[name]:
+            assert np.allclose(pl[name][key], pl2[name][key], rtol=1e-9, atol=1e-13)
+    # the planes of an axis average to the lattice value
+    assert np.mean(sd["X"]["S"]) == pytest.approx(np.mean(rows[1:, 5]), rel=1e-11)
+    lat.close()
+    # the series travel in the state file: stopped after sample 2 and continued
+    import shutil
+    _, _, _, out = _run(tmp_path / "c", keys, "\tGETSDIFF = 1\n", args=["--save-state", "--save-every", "1e9", "--stop-at", "2"])
+    qcg = re.findall(r"state file: (\S+)", out)[-1]
+    (tmp_path / "d").mkdir()
+    shutil.copy(qcg, tmp_path / "d" / "s.qcg")
+    text3, _, rows3, _ = _run(tmp_path / "d", keys, "\tGETSDIFF = 1\n", args=["--load", "s.qcg"])
+    assert np.array_equal(rows3, rows)
+    sd3 = _profile_rows(text3, "Differentiated S data")
+    pl3 = _profile_rows(text3, "Differentiated Polyakov loop data")
+    for name in "XYZ":
+        for key in sd[name]:
+            assert np.array_equal(sd3[name][key], sd[name][key])
+        for key in pl[name]:
+            assert np.array_equal(pl3[name][key], pl[name][key])

@@ -284,3 +284,30 @@ def test_errors_are_status_codes_not_exits():
             c.update(2, 0)
         with pytest.raises(q.QcdError):
             c.upload(np.zeros((12, 100, 4)))              # rowsize < sites
+
+
+@pytest.mark.parametrize("group,L", [(3, (6, 4, 8, 4)), (2, (4, 8, 6, 6))])
+def test_plane_profiles_match_checker(group, L):
+    """Plane-resolved plaquette and Polyakov-loop sums (the reference's lattice_action_diff_* and
+    lattice_polyakov_diff_* kernels; device path only there, so no reference output to pin them):
+    against the checker plane by plane to 1e-12, and their totals against the lattice sums."""
+    import qcdgpu_amd as q
+    beta = 5.9 if group == 3 else 2.4
+    lat = ol.Lattice(group, L, beta, nhit=6, ints=1, rng_mode=ol.RNG_PERSITE)
+    with q.Context(group=group, L=L, beta=beta, nhit=6) as c:
+        c.init_lattice()
+        c.sweep(2)
+        lat.sweep(2)
+        sums = c.plaquette_sums()
+        psums = c.polyakov_sums()
+        for axis in range(3):
+            got, want = c.plaquette_profile_sums(axis), lat.plaquette_profile_sums(axis)
+            assert got.shape == (L[axis], 2)
+            assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+            assert np.allclose(got.sum(axis=0), sums, rtol=1e-12)
+            gp, wp = c.polyakov_profile_sums(axis), lat.polyakov_profile_sums(axis)
+            assert np.allclose(gp, wp, rtol=1e-10, atol=1e-12)
+            assert np.allclose(gp.sum(axis=0), psums[:2], rtol=1e-11, atol=1e-12)
+        with pytest.raises(q.QcdError):
+            c.plaquette_profile_sums(3)
+    lat.close()

@@ -216,3 +216,29 @@ def test_on_update_properties():
     acc = lat.acceptance[1]
     assert 0 <= acc <= 5 * half
     lat.close()
+
+
+def test_profiles_add_up_to_the_lattice_sums():
+    """Plane-resolved plaquette and Polyakov sums: every axis' planes add up to the lattice sums,
+    and a cold lattice gives the same value in every plane."""
+    L = (4, 6, 4, 6)
+    lat = ol.Lattice(3, L, 5.8, nhit=5, ints=1, rng_mode=ol.RNG_PERSITE)
+    for axis in range(3):
+        p = lat.plaquette_profile_sums(axis)
+        others = np.prod(L) // L[axis]
+        assert np.allclose(p, 9.0 * others)
+        q = lat.polyakov_profile_sums(axis)
+        assert np.allclose(q[:, 0], 3.0 * others / L[3]) and np.allclose(q[:, 1], 0.0)
+    lat.sweep(2)
+    sites = np.prod(L)
+    plq = lat.plaquette()
+    pol = lat.polyakov()
+    for axis in range(3):
+        p = lat.plaquette_profile_sums(axis).sum(axis=0)
+        assert p[0] / (3 * sites) == pytest.approx(plq[0], rel=1e-12)
+        assert p[1] / (3 * sites) == pytest.approx(plq[1], rel=1e-12)
+        q = lat.polyakov_profile_sums(axis).sum(axis=0)
+        n123 = L[0] * L[1] * L[2]
+        assert q[0] / (3 * n123) == pytest.approx(pol[0], rel=1e-11, abs=1e-14)
+        assert q[1] / (3 * n123) == pytest.approx(pol[1], rel=1e-11, abs=1e-14)
+    lat.close()
