@@ -1017,6 +1017,59 @@ void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out)
     (void)slice;
 }
 
+/* F_mu_nu traces (SU(N)/suncl/su3cpu.cpp:1212-1381; device: lattice_retrace_plaquette3_F,
+ * SU(N)/suncl/su3_measurements_cl.cl:550-589): per site and plane the plaquette matrix
+ * P = U_mu(x) U_nu(x+mu) U_mu(x+nu)^+ U_nu(x)^+ times the Gell-Mann matrix lambda_a,
+ * F_re = Im Tr(P lambda_a) / 2, F_im = -Re Tr(P lambda_a) / 2, summed over the sites.
+ * field 0: planes xy, xz, yz (get_Fmunu); field 1: planes xt, yt, zt (get_F0mu).
+ * out[4*0 .. ] layout: for a in (index1, index2), for the three planes: (re, im).  SU(3) only. */
+static qo_su3 gell_mann(int index)
+{
+    /* su3cpu.cpp:775-920 */
+    qo_su3 a;
+    memset(&a, 0, sizeof(a));
+    switch (index) {
+        case 1: a.u2.re = 1.0; a.v1.re = 1.0; break;
+        case 2: a.u2.im = -1.0; a.v1.im = 1.0; break;
+        case 3: a.u1.re = 1.0; a.v2.re = -1.0; break;
+        case 4: a.u3.re = 1.0; a.w1.re = 1.0; break;
+        case 5: a.u3.im = -1.0; a.w1.im = 1.0; break;
+        case 6: a.v3.re = 1.0; a.w2.re = 1.0; break;
+        case 7: a.v3.im = -1.0; a.w2.im = 1.0; break;
+        case 8:
+            a.u1.re = 0.57735026918962576450914878050196;
+            a.v2.re = 0.57735026918962576450914878050196;
+            a.w3.re = -1.1547005383792515290182975610039;
+            break;
+        default: a.u1.re = a.v2.re = a.w3.re = 1.0; break;
+    }
+    return a;
+}
+
+void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, double out[12])
+{
+    const int nd = lat->nd;
+    const qo_su3 *tab = (const qo_su3 *)lat->links;
+    const qo_su3 l1 = gell_mann(index1), l2 = gell_mann(index2);
+    static const int planes[2][3][2] = { { {0, 1}, {0, 2}, {1, 2} }, { {0, 3}, {1, 3}, {2, 3} } };
+    for (int i = 0; i < 12; i++) out[i] = 0.0;
+    if (lat->group != 3) return;
+    for (int gid = 0; gid < lat->sites; gid++)
+        for (int k = 0; k < 3; k++) {
+            const int dir = planes[field][k][0], dir1 = planes[field][k][1];
+            int g1 = qo_neighbour(lat->L, gid, dir);
+            int g2 = qo_neighbour(lat->L, gid, dir1);
+            qo_su3 m1 = tab[gid * nd + dir], m2 = tab[g1 * nd + dir1];
+            qo_su3 m3 = qo_herm3(&tab[g2 * nd + dir]), m4 = qo_herm3(&tab[gid * nd + dir1]);
+            qo_su3 p = qo_mul3(&m1, &m2); p = qo_mul3(&p, &m3); p = qo_mul3(&p, &m4);
+            qo_su3 t1 = qo_mul3(&p, &l1), t2 = qo_mul3(&p, &l2);
+            out[2 * k] += (t1.u1.im + t1.v2.im + t1.w3.im) / 2;
+            out[2 * k + 1] += -(t1.u1.re + t1.v2.re + t1.w3.re) / 2;
+            out[6 + 2 * k] += (t2.u1.im + t2.v2.im + t2.w3.im) / 2;
+            out[6 + 2 * k + 1] += -(t2.u1.re + t2.v2.re + t2.w3.re) / 2;
+        }
+}
+
 void qo_estimates(const double *data, int n, double *mean_out, double *var_out)
 {
     /* lattice_estimates, analysis_cpp.cpp:81-93 -- sample 0 excluded, biased variance */

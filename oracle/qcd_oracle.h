@@ -9,9 +9,11 @@
  * checked against the compiled reference (oracle/_ref/qcdgpu_cpu, built from
  * the reference's own sources by oracle/Makefile) through the fixtures under
  * tests/golden/, in the sequential-stream ("seq") and deterministic ("gid")
- * modes.  The Polyakov loop has no runnable reference (its only CPU twin needs
- * an OpenCL device at run time): that one function is "parity unpinned" and is
- * checked by closed forms only.
+ * modes.  The Polyakov loop, the Wilson loop and the F_mu_nu traces are pinned
+ * against the reference's CPU re-measurement of a configuration
+ * (SU(N)/suncl/su3cpu.cpp:1616-1704, compiled into oracle/_ref/qcdgpu_su3_check by
+ * `make ref_su3`; fixtures tests/golden/chk_su3_*) for SU(3); their SU(2) forms,
+ * the hot start, the overrelaxation and the plane profiles are "parity unpinned".
  */
 #ifndef QCD_ORACLE_H
 #define QCD_ORACLE_H
@@ -128,6 +130,10 @@ void qo_polyakov(const qo_lattice *lat, double out[4]);
  * only: "parity unpinned" */
 void qo_plaquette_profile_sums(const qo_lattice *lat, int axis, double *out);
 void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out);
+
+/* F_mu_nu traces summed over the sites, SU(3): field 0 = planes xy,xz,yz, 1 = xt,yt,zt; out = for
+ * (index1, index2) x three planes x (re, im); SU(N)/suncl/su3cpu.cpp:1212-1381 */
+void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, double out[12]);
 
 /* statistics, SU(N)/suncpp/Measurements/analysis_cpp.cpp:81-93 */
 void qo_estimates(const double *data, int n, double *mean, double *variance);

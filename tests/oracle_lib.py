@@ -36,6 +36,7 @@ def _load():
     lib.qo_plaquette.argtypes = [P, pd]
     lib.qo_action.argtypes = [P, pd]
     lib.qo_polyakov.argtypes = [P, pd]
+    lib.qo_fmunu_sums.argtypes = [P, I, I, I, pd]
     lib.qo_plaquette_profile_sums.argtypes = [P, I, pd]
     lib.qo_polyakov_profile_sums.argtypes = [P, I, pd]
     lib.qo_simulate.argtypes = [P, I, I, I, pd, pd]
@@ -128,6 +129,11 @@ class Lattice:
     def polyakov(self):
         out = (C.c_double * 4)()
         lib.qo_polyakov(self.h, out)
+        return np.array(out[:])
+
+    def fmunu_sums(self, field, index1=3, index2=8):
+        out = (C.c_double * 12)()
+        lib.qo_fmunu_sums(self.h, field, index1, index2, out)
         return np.array(out[:])
 
     def plaquette_profile_sums(self, axis):

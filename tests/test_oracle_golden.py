@@ -242,3 +242,41 @@ def test_profiles_add_up_to_the_lattice_sums():
         assert q[0] / (3 * n123) == pytest.approx(pol[0], rel=1e-11, abs=1e-14)
         assert q[1] / (3 * n123) == pytest.approx(pol[1], rel=1e-11, abs=1e-14)
     lat.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# SU(3) observables that the reference's sequential CPU program does not have, pinned against its
+# CPU re-measurement code (fixtures minted by oracle/make_golden_su3_check.py)
+
+CHK_CASES = sorted(f for f in os.listdir(ol.GOLDEN_DIR) if f.startswith("chk_su3_") and f.endswith(".json"))
+
+
+def load_check_case(fname):
+    with open(os.path.join(ol.GOLDEN_DIR, fname)) as f:
+        doc = json.load(f)
+    table = np.load(os.path.join(ol.GOLDEN_DIR, doc["table"]), allow_pickle=False)
+    return doc, table
+
+
+def expected_fmunu(doc):
+    e = doc["expected"]
+    return np.array([e["F_%s_%s_%s" % (p, a, c)] for a in ("3", "8") for p in "abc" for c in ("re", "im")])
+
+
+@pytest.mark.parametrize("fname", CHK_CASES)
+def test_polyakov_wilson_fmunu_match_reference_cpu_code(fname):
+    doc, table = load_check_case(fname)
+    e = doc["expected"]
+    lat = ol.Lattice(3, doc["L"], doc["beta"], nhit=1, ints=1, rng_mode=ol.RNG_PERSITE)
+    lat.import_table(table)
+    plq = lat.plaquette()
+    act = lat.action()
+    assert plq[0] == pytest.approx(e["Plq_spat"], rel=1e-13) and plq[1] == pytest.approx(e["Plq_temp"], rel=1e-13)
+    assert act[0] == pytest.approx(e["S_spat"], rel=1e-12) and act[1] == pytest.approx(e["S_temp"], rel=1e-12)
+    pol = lat.polyakov()
+    want = [e["Polyakov_loop"], e["Polyakov_loop_im"], e["Polyakov_loop_P2"], e["Polyakov_loop_P4"]]
+    assert np.allclose(pol, want, rtol=1e-12, atol=1e-15)
+    assert lat.wilson_loop(doc["wilson_R"], doc["wilson_T"]) == pytest.approx(e["Wilson_loop"], rel=1e-12)
+    f = lat.fmunu_sums(doc["field"] - 1, doc["index1"], doc["index2"]) / np.prod(doc["L"])
+    assert np.allclose(f, expected_fmunu(doc), rtol=1e-11, atol=1e-15)
+    lat.close()
