@@ -120,6 +120,16 @@ int qcd_measure_polyakov(qcd_ctx *ctx, double out[4]);
 int qcd_measure_plaquette_sums(qcd_ctx *ctx, double sums[2]);
 int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
 
+/* kernel_run(sun_measurement_plq_id) built with FMUNU or F0MU + its reduce kernel (suncl.cpp:5478-5483;
+ * kernel lattice_measurement_plq, sun_measurements_cl.cl:712-1175; CPU twin su3cpu.cpp:1212-1381):
+ * F_re = Im Tr(P lambda_a)/2, F_im = -Re Tr(P lambda_a)/2 of the plaquette matrix P, per plane.
+ * field 0 = planes xy, xz, yz (FMUNU, "H field"), 1 = xt, yt, zt (F0MU, "E field"); index1 in
+ * {1,2,3,4}, index2 in {5,6,7,8} in the reference (FMUNU1.. keys), any 1..8 here.  out = for
+ * (index1, index2) x three planes x (re, im).  qcd_measure_fmunu: averages over this context's
+ * sites; _sums: raw sums (slabs: add over contexts, divide by the full volume).  SU(3) only. */
+int qcd_measure_fmunu(qcd_ctx *ctx, int field, int index1, int index2, double out[12]);
+int qcd_measure_fmunu_sums(qcd_ctx *ctx, int field, int index1, int index2, double sums[12]);
+
 /* kernel_run(sun_action_diff_{x,y,z}_id) / kernel_run(sun_polyakov_diff_{x,y,z}_id) with their reduce
  * kernels (suncl.cpp:5432-5449, 5458-5476; kernels lattice_action_diff_*, sun_measurements_cl.cl:186-616,
  * lattice_polyakov_diff_*, polyakov.cl:142-402): profiles along a space axis (0 x, 1 y, 2 z).

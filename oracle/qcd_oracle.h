@@ -11,8 +11,8 @@
  * tests/golden/, in the sequential-stream ("seq") and deterministic ("gid")
  * modes.  The Polyakov loop, the Wilson loop and the F_mu_nu traces are pinned
  * against the reference's CPU re-measurement of a configuration
- * (SU(N)/suncl/su3cpu.cpp:1616-1704, compiled into oracle/_ref/qcdgpu_su3_check by
- * `make ref_su3`; fixtures tests/golden/chk_su3_*) for SU(3); their SU(2) forms,
+ * (SU(N)/suncl/su3cpu.cpp:1616-1704, compiled into oracle/_ref/qcdgpu_sun_check by
+ * `make ref_sun`; fixtures tests/golden/chk_su3_*, chk_su2_*; the F traces for SU(3) only);
  * the hot start, the overrelaxation and the plane profiles are "parity unpinned".
  */
 #ifndef QCD_ORACLE_H

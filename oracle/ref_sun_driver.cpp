@@ -1,32 +1,36 @@
-// ref_su3_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+// ref_sun_driver.cpp -- TEST INFRASTRUCTURE ONLY.
 //
-// Calls the reference's own CPU re-measurement of an SU(3) configuration,
-// SU3_CPU::SU::lattice_check_cpu (SU(N)/suncl/su3cpu.cpp:1616-1704): plaquettes, the F_mu_nu traces,
-// the Wilson loop and the Polyakov loop, computed on the host from a link table in the reference's
-// device layout.  The reference's sources are compiled where they lie (Makefile target `ref_su3`);
+// Calls the reference's own CPU re-measurement of an SU(3) or SU(2) configuration,
+// SU3_CPU::SU::lattice_check_cpu (SU(N)/suncl/su3cpu.cpp:1616-1704) resp. SU2_CPU::SU::lattice_check_cpu
+// (SU(N)/suncl/su2cpu.cpp:1120-1210): plaquettes, the F_mu_nu traces, the Wilson loop and the Polyakov loop, computed on the host from a link table in the reference's
+// device layout.  The reference's sources are compiled where they lie (Makefile target `ref_sun`);
 // this file only fills in the public members those functions read -- no OpenCL device is touched
 // (model's and GPU's constructors only initialise members, SU(N)/suncl/suncl.cpp:142-214).
 //
-//   qcdgpu_su3_check n1 n2 n3 n4 rowsize beta fmunu(0 none,1 H,2 E) index1 index2 wilsonR wilsonT table.bin
+//   qcdgpu_sun_check group n1 n2 n3 n4 rowsize beta fmunu(0 none,1 H,2 E) index1 index2 wilsonR wilsonT table.bin
 //
-// table.bin: 12 rows of rowsize double4 (SU(N)/suncl/su3_matrix_memory.cl:42-176).  Prints one
+// table.bin: 12 (SU(3)) or 4 (SU(2)) rows of rowsize double4 (SU(N)/suncl/su3_matrix_memory.cl:42-176,
+// su2_matrix_memory.cl:55-142).  Prints one
 // "name value" line per quantity, "%.17g".
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "suncl/suncl.h"
+#include "suncl/su2cpu.h"
 #include "suncl/su3cpu.h"
 
 int main(int argc, char** argv)
 {
-    if (argc != 13) {
-        fprintf(stderr, "usage: %s n1 n2 n3 n4 rowsize beta fmunu index1 index2 wilsonR wilsonT table.bin\n", argv[0]);
+    if (argc != 14) {
+        fprintf(stderr, "usage: %s group n1 n2 n3 n4 rowsize beta fmunu index1 index2 wilsonR wilsonT table.bin\n", argv[0]);
         return 2;
     }
+    const int group = atoi(argv[1]);
+    argv++;
     model_CL::model* lat = new model_CL::model;
     lat->lattice_nd = 4;
-    lat->lattice_group = 3;
+    lat->lattice_group = group;
     for (int i = 0; i < 4; i++) lat->lattice_domain_size[i] = lat->lattice_full_size[i] = atoi(argv[1 + i]);
     const int n1 = lat->lattice_full_size[0], n2 = lat->lattice_full_size[1], n3 = lat->lattice_full_size[2], n4 = lat->lattice_full_size[3];
     const unsigned int rowsize = (unsigned int)atoi(argv[5]);
@@ -55,7 +59,7 @@ int main(int argc, char** argv)
     lat->rowsize = rowsize;
     lat->rowsize4 = 4 * rowsize;
 
-    const size_t words = (size_t)12 * rowsize * 4 * 2;   // 32-bit words
+    const size_t words = (size_t)(group == 3 ? 12 : 4) * rowsize * 4 * 2;   // 32-bit words
     std::vector<unsigned int> table(words);
     FILE* f = fopen(argv[12], "rb");
     if (!f || fread(table.data(), 4, words, f) != words) {
@@ -65,9 +69,15 @@ int main(int argc, char** argv)
     fclose(f);
     lat->lattice_pointer_last = table.data();
 
-    SU3_CPU::SU* cpu = new SU3_CPU::SU;
-    cpu->GPU0 = lat->GPU0;
-    cpu->lattice_check_cpu(lat);
+    if (group == 3) {
+        SU3_CPU::SU* cpu = new SU3_CPU::SU;
+        cpu->GPU0 = lat->GPU0;
+        cpu->lattice_check_cpu(lat);
+    } else {
+        SU2_CPU::SU* cpu = new SU2_CPU::SU;
+        cpu->GPU0 = lat->GPU0;
+        cpu->lattice_check_cpu(lat);
+    }
 
     static const struct { const char* name; int idx; } q[] = {
         {"S_spat", DM_S_spat}, {"S_temp", DM_S_temp}, {"Plq_spat", DM_Plq_spat}, {"Plq_temp", DM_Plq_temp},

@@ -51,7 +51,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
            "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
            "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range",
-           "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
+           "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
            "qcd_on_download"]
@@ -111,6 +111,8 @@ def _load():
     lib.qcd_rng_state_bytes.argtypes = [P]
     lib.qcd_rng_state_download.argtypes = [P, C.c_void_p, C.c_size_t]
     lib.qcd_rng_state_upload.argtypes = [P, C.c_void_p, C.c_size_t]
+    lib.qcd_measure_fmunu.argtypes = [P, I, I, I, pd]
+    lib.qcd_measure_fmunu_sums.argtypes = [P, I, I, I, pd]
     lib.qcd_measure_plaquette_profile_sums.argtypes = [P, I, pd]
     lib.qcd_measure_polyakov_profile_sums.argtypes = [P, I, pd]
     lib.qcd_on_create.argtypes = [C.POINTER(P), C.POINTER(OnParams)]
@@ -257,6 +259,13 @@ class Context:
         out = C.c_double()
         _check(lib.qcd_measure_wilson(self.h, R, T, C.byref(out)))
         return out.value
+
+    def fmunu(self, field, index1=3, index2=8, sums=False):
+        """F_mu_nu traces: for (index1, index2) x three planes x (re, im); field 0 = xy,xz,yz, 1 = xt,yt,zt."""
+        out = (C.c_double * 12)()
+        fn = lib.qcd_measure_fmunu_sums if sums else lib.qcd_measure_fmunu
+        _check(fn(self.h, field, index1, index2, out))
+        return np.array(out[:])
 
     def _profile_extent(self, axis):
         return self.params.nx_local if axis == 0 else self.L[axis]

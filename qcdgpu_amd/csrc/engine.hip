@@ -491,8 +491,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
         tryhip(hipMalloc(&c->gidr, (size_t)6 * g.nx * g.gslice * sizeof(float)), "hipMalloc(gid table)");
     // the profile measurements need one pair per plane and up to 64 partials per plane
     const int max_ext = g.nx > g.ny ? (g.nx > g.nz ? g.nx : g.nz) : (g.ny > g.nz ? g.ny : g.nz);
-    c->partial_len = 2L * c->npartial > 64L * max_ext ? 2L * c->npartial : 64L * max_ext;
-    c->result_len = 2 * max_ext > 8 ? 2 * max_ext : 8;
+    c->partial_len = 6L * c->npartial > 64L * max_ext ? 6L * c->npartial : 64L * max_ext;
+    c->result_len = 2 * max_ext > 16 ? 2 * max_ext : 16;
     tryhip(hipMalloc(&c->partial, (size_t)c->partial_len * sizeof(double2)), "hipMalloc(partials)");
     tryhip(hipMalloc(&c->result_dev, c->result_len * sizeof(double)), "hipMalloc(result)");
     tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double)), "hipHostMalloc(result)");
@@ -725,6 +725,33 @@ int qcd_measure_wilson(qcd_ctx* c, int R, int T, double* out)
     rc = reduce_partials(c, nb, 1, s);
     if (rc) return rc;
     *out = s[0] / (3.0 * (double)c->g.gsites);   // SU(N)/suncl/suncl.cpp:1606-1611
+    return QCD_OK;
+}
+
+int qcd_measure_fmunu_sums(qcd_ctx* c, int field, int index1, int index2, double sums[12])
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (c->p.group != 3) return fail(QCD_ERR_UNSUPPORTED, "the F_mu_nu traces are implemented for SU(3) only");
+    if (field != 0 && field != 1) return fail(QCD_ERR_INVALID, "field %d is not 0 (xy, xz, yz) or 1 (xt, yt, zt)", field);
+    if (index1 < 1 || index1 > 8 || index2 < 1 || index2 > 8) return fail(QCD_ERR_INVALID, "Gell-Mann indices %d, %d outside 1..8", index1, index2);
+    if (!sums) return fail(QCD_ERR_INVALID, "null output");
+    if (6L * c->npartial > c->partial_len) return fail(QCD_ERR_UNSUPPORTED, "reduction buffer too small");
+    Timed tm(c, 1);
+    hipLaunchKernelGGL((k_fmunu<MEAS_BLOCK>), dim3(c->npartial), dim3(MEAS_BLOCK), 0, c->stream, c->U, c->g, field, index1, index2,
+                       c->partial, c->npartial);
+    HIP_TRY(hipGetLastError());
+    rc = reduce_partials(c, c->npartial, 6, sums);
+    if (rc) return rc;
+    return tm.finish();
+}
+
+int qcd_measure_fmunu(qcd_ctx* c, int field, int index1, int index2, double out[12])
+{
+    int rc = qcd_measure_fmunu_sums(c, field, index1, index2, out);
+    if (rc) return rc;
+    const double sites = 2.0 * c->g.vh_int;
+    for (int i = 0; i < 12; i++) out[i] /= sites;
     return QCD_OK;
 }
 

@@ -165,6 +165,16 @@ void model::lattice_get_init_file(char* file)
         if (!strcmp(v, "GETRETRACE")) get_plaquettes_avr = true;
         if (!strcmp(v, "PL_LEVEL")) PL_level = p.iVarVal;
         if (!strcmp(v, "GETSDIFF")) get_actions_diff = true;
+        // SU(N)/suncl/suncl.cpp:412-452, 2104-2112
+        if (!strcmp(v, "TURNOFFFMUNU")) get_Fmunu = get_F0mu = false;
+        if (!strcmp(v, "FMUNU")) { get_Fmunu = true; get_F0mu = false; }
+        if (!strcmp(v, "F0MU")) { get_F0mu = true; get_Fmunu = false; }
+        if (!strcmp(v, "FMUNU1")) Fmunu_index1 = 1;
+        if (!strcmp(v, "FMUNU2")) Fmunu_index1 = 2;
+        if (!strcmp(v, "FMUNU4")) Fmunu_index1 = 4;
+        if (!strcmp(v, "FMUNU5")) Fmunu_index2 = 5;
+        if (!strcmp(v, "FMUNU6")) Fmunu_index2 = 6;
+        if (!strcmp(v, "FMUNU7")) Fmunu_index2 = 7;
         if (!strcmp(v, "WILSONR")) wilson_R = p.iVarVal;
         if (!strcmp(v, "WILSONT")) wilson_T = p.iVarVal;
     }
@@ -232,6 +242,8 @@ const char* model::lattice_make_header(void)
     // model_make_header, SU(N)/suncl/suncl.cpp:779-795
     j += snprintf(buf + j, n - j, " Wilson loop R               : %i\n", wilson_R);
     j += snprintf(buf + j, n - j, " Wilson loop T               : %i\n", wilson_T);
+    if (get_Fmunu) j += snprintf(buf + j, n - j, " FMUNU(%u, %u)\n", Fmunu_index1, Fmunu_index2);   // suncl.cpp:784-787
+    if (get_F0mu) j += snprintf(buf + j, n - j, " F0MU(%u, %u)\n", Fmunu_index1, Fmunu_index2);
     j += snprintf(buf + j, n - j, " BETA                        : %16.13e\n", BETA);
     j += snprintf(buf + j, n - j, " PHI   (lambda_3)            : %16.13e\n", PHI);
     j += snprintf(buf + j, n - j, " OMEGA (lambda_8)            : %16.13e\n", OMEGA);
@@ -255,6 +267,7 @@ void model::lattice_init(void)
     if (lattice_nd != 4) throw model_error("ND must be 4");
     if (precision != model_precision_double) throw model_error("only double precision is implemented");
     if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
+    if ((get_Fmunu || get_F0mu) && lattice_group != 3) throw model_error("FMUNU / F0MU are implemented for SU(3) only");
     if (get_wilson_loop && lattice_Nparts > 1) throw model_error("the Wilson loop is measured on an uncut lattice only (GETWILSON with N1 = {..})");
     // initialize_CPU (SU(N)/random/random.cpp:174-182): RANDSERIES = 0 means "seed from the clock"
     PRNG0->PRNG_srandtime = (unsigned int)time(NULL);
@@ -350,6 +363,17 @@ void model::measure(int index)
     if (get_wilson_loop) check(qcd_measure_wilson(SubLat[0].ctx, wilson_R, wilson_T, &wl_[index]), "qcd_measure_wilson");
     derive_sample(index);
     if (get_actions_diff || PL_level > 2) measure_profiles(index);
+    if (get_Fmunu || get_F0mu) {
+        // lattice_analysis_Fmunu, SU(N)/suncl/suncl.cpp:1000-1042: site averages over the whole lattice
+        double f[12] = {0};
+        for (auto& s : SubLat) {
+            double part[12];
+            check(qcd_measure_fmunu_sums(s.ctx, get_F0mu ? 1 : 0, Fmunu_index1, Fmunu_index2, part), "qcd_measure_fmunu_sums");
+            for (int i = 0; i < 12; i++) f[i] += part[i];
+        }
+        const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
+        for (int i = 0; i < 12; i++) fmunu_[i][index] = f[i] / v;
+    }
 }
 
 // S(x), S(y), S(z) and the Polyakov loop plane by plane (lattice_analysis_Action_diff,
@@ -826,6 +850,8 @@ void model::lattice_simulate(void)
     for (int i = 0; i < 2; i++) plq_raw_[i].assign(ITER, 0.0);
     for (int i = 0; i < 4; i++) pl_raw_[i].assign(ITER, 0.0);
     wl_.assign(ITER, 0.0);
+    for (int i = 0; i < 12; i++) fmunu_[i].assign((get_Fmunu || get_F0mu) ? ITER : 0, 0.0);
+    if (INIT == 0 && (get_Fmunu || get_F0mu)) throw model_error("state files do not carry the F_mu_nu series: continue without FMUNU / F0MU");
     for (int a = 0; a < 3; a++) {
         s_diff_[a].assign(get_actions_diff ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);
         pl_diff_[a].assign(PL_level > 2 ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);
@@ -894,7 +920,36 @@ void model::lattice_analysis(void)
     Analysis[DM_Polyakov_loop_P4].data = pl_[3];
     Analysis[DM_Wilson_loop].data = wl_;
     lattice_data_analysis(&Analysis[DM_Wilson_loop]);
-    for (int i = 1; i <= DM_max; i++) lattice_data_analysis(&Analysis[i]);
+    if (get_Fmunu || get_F0mu) {
+        // names and the |F| columns: SU(N)/suncl/suncl.cpp:1004-1063, data_analysis.cpp:186-206
+        static const char* xyz[3] = {"xy", "xz", "yz"};
+        static const char* xyzt[3] = {"xt", "yt", "zt"};
+        static const char* reim[2] = {"re", "im"};
+        for (int i = 0; i < 6; i++) {
+            char buf[32];
+            snprintf(buf, sizeof(buf), "Fmunu_%s_%u_%s", get_Fmunu ? xyz[i / 2] : xyzt[i / 2], Fmunu_index1, reim[i & 1]);
+            fmunu_names_[i] = buf;
+            snprintf(buf, sizeof(buf), "Fmunu_%s_%u_%s", get_Fmunu ? xyz[i / 2] : xyzt[i / 2], Fmunu_index2, reim[i & 1]);
+            fmunu_names_[6 + i] = buf;
+            Analysis[DM_Fmunu_3 + i].data = fmunu_[i];
+            Analysis[DM_Fmunu_8 + i].data = fmunu_[6 + i];
+        }
+        for (int a = 0; a < 2; a++)
+            for (int c = 0; c < 2; c++) {
+                char buf[32];
+                snprintf(buf, sizeof(buf), "%s_abs_%1u_%s", get_Fmunu ? "Fmunu" : "F0mu", a ? Fmunu_index2 : Fmunu_index1, reim[c]);
+                fmunu_names_[12 + 2 * a + c] = buf;
+                std::vector<double>& d = Analysis[DM_Fmunu_abs_3_re + 2 * a + c].data;
+                d.assign(ITER, 0.0);
+                for (int i = 0; i < ITER; i++) {
+                    const double x = fmunu_[6 * a + c][i], y = fmunu_[6 * a + 2 + c][i], z = fmunu_[6 * a + 4 + c][i];
+                    d[i] = sqrt(x * x + y * y + z * z);
+                }
+            }
+        for (int i = 0; i < 16; i++) Analysis[DM_Fmunu_3 + i].data_name = fmunu_names_[i].c_str();
+    }
+    for (int i = 1; i <= DM_max; i++)
+        if (!Analysis[i].data.empty()) lattice_data_analysis(&Analysis[i]);
 }
 
 const char* model::lattice_make_header2(void)
@@ -923,6 +978,13 @@ const char* model::lattice_make_header2(void)
         j += snprintf(buf + j, n - j, " Variance %-16s: % 16.13e\n", Analysis[DM_Wilson_loop].data_name, Analysis[DM_Wilson_loop].variance);
     }
     j += snprintf(buf + j, n - j, " ***************************************************\n");
+    if (get_Fmunu || get_F0mu) {
+        for (int i = 0; i < 16; i++)
+            j += snprintf(buf + j, n - j, " Mean %-20s: % 16.13e\n", Analysis[DM_Fmunu_3 + i].data_name, Analysis[DM_Fmunu_3 + i].mean_value);
+        for (int i = 0; i < 16; i++)
+            j += snprintf(buf + j, n - j, " Variance %-16s: % 16.13e\n", Analysis[DM_Fmunu_3 + i].data_name, Analysis[DM_Fmunu_3 + i].variance);
+        j += snprintf(buf + j, n - j, " ***************************************************\n");
+    }
     for (int idx : order)
         j += snprintf(buf + j, n - j, " GPU last %-16s: % 16.13e\n", Analysis[idx].data_name, Analysis[idx].GPU_last_value);
     header += buf;
@@ -952,6 +1014,8 @@ void model::lattice_write_results(void)
     if (get_actions_avr) { cols.push_back(DM_S_spat); cols.push_back(DM_S_temp); cols.push_back(DM_S_total); }
     if (PL_level > 0) { cols.push_back(DM_Polyakov_loop); cols.push_back(DM_Polyakov_loop_im); }
     if (PL_level > 1) { cols.push_back(DM_Polyakov_loop_P2); cols.push_back(DM_Polyakov_loop_P4); }
+    if (get_Fmunu || get_F0mu)
+        for (int i = 0; i < 16; i++) cols.push_back(DM_Fmunu_3 + i);   // suncl.cpp:1812-1818, 1845-1848
     for (int c : cols) fprintf(stream, "%-21s ", Analysis[c].data_name);
     fprintf(stream, "\n");
     fprintf(stream, " ***************************************************\n");

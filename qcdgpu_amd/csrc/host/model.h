@@ -37,7 +37,15 @@ namespace model_HIP {
 #define DM_Polyakov_loop_im 8
 #define DM_Polyakov_loop_P2 9
 #define DM_Polyakov_loop_P4 10
-#define DM_max 10
+// F_mu_nu block (SU(N)/suncl/suncl.h:235-252): three planes x (re, im) for the first and the second
+// Gell-Mann index, then the four |F| columns
+#define DM_Fmunu_3 11
+#define DM_Fmunu_8 17
+#define DM_Fmunu_abs_3_re 23
+#define DM_Fmunu_abs_3_im 24
+#define DM_Fmunu_abs_8_re 25
+#define DM_Fmunu_abs_8_im 26
+#define DM_max 26
 
 struct model_error : std::runtime_error {
     using std::runtime_error::runtime_error;
@@ -122,6 +130,10 @@ public:
     bool get_actions_avr = true;
     bool get_plaquettes_avr = true;
     bool get_wilson_loop = false;  // GETWILSON: the wilson_R x wilson_T loop as a further column
+    bool get_Fmunu = false;        // FMUNU: F_mu_nu traces of the planes xy, xz, yz ("H field")
+    bool get_F0mu = false;         // F0MU: of the planes xt, yt, zt ("E field")
+    int Fmunu_index1 = 3;          // Gell-Mann index of the first trace (FMUNU1, FMUNU2, FMUNU4; default 3)
+    int Fmunu_index2 = 8;          // of the second (FMUNU5, FMUNU6, FMUNU7; default 8)
     bool get_actions_diff = false; // S(x), S(y), S(z): the action plane by plane (suncl.h:144; init key GETSDIFF is an addition)
     bool profiling = false;        // GPU_debug.profiling
     // lattice state files (SU(N)/suncl/suncl.h:80,154-175; defaults of main, QCDGPU.cpp:203,215)
@@ -173,6 +185,8 @@ public:
 private:
     std::vector<double> plq_[3], act_[3], pl_[4];
     std::vector<double> wl_;
+    std::vector<double> fmunu_[12];                // per sample: the twelve F_mu_nu averages
+    std::string fmunu_names_[16];
     // plane-resolved series, [axis][plane * ITER + sample]: S_total_diff and (PL, PL_im) diff
     std::vector<double> s_diff_[3], pl_diff_[3], pl_diff_im_[3];
     void measure_profiles(int index);

@@ -1150,6 +1150,67 @@ __global__ __launch_bounds__(BLOCK) void k_polyakov(const double2* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// F_mu_nu traces (kernel lattice_measurement_plq with FMUNU / F0MU, SU(N)/suncl/sun_measurements_cl.cl:712-1175;
+// lattice_retrace_plaquette3_F, SU(N)/suncl/su3_measurements_cl.cl:550-589; CPU twin
+// SU(N)/suncl/su3cpu.cpp:1212-1381): per site and plane the plaquette matrix
+// P = U_mu(x) U_nu(x+mu) U_mu(x+nu)^+ U_nu(x)^+ and  F_re = Im Tr(P lambda_a) / 2,
+// F_im = -Re Tr(P lambda_a) / 2  for two Gell-Mann matrices.  field 0: planes xy, xz, yz; field 1:
+// planes xt, yt, zt.  partial[(3 * a + plane) * nblocks + block] = (sum F_re, sum F_im).
+
+// Tr(P lambda_index), Gell-Mann matrices as su3cpu.cpp:775-920 writes them
+__device__ __forceinline__ cplx trace_gell_mann(const su3& p, int index)
+{
+    switch (index) {
+        case 1: return cadd(p.e[0][1], p.e[1][0]);
+        case 2: { const cplx d = csub(p.e[0][1], p.e[1][0]); return mk(-d.im, d.re); }   // i (P12 - P21)
+        case 3: return csub(p.e[0][0], p.e[1][1]);
+        case 4: return cadd(p.e[0][2], p.e[2][0]);
+        case 5: { const cplx d = csub(p.e[0][2], p.e[2][0]); return mk(-d.im, d.re); }
+        case 6: return cadd(p.e[1][2], p.e[2][1]);
+        case 7: { const cplx d = csub(p.e[1][2], p.e[2][1]); return mk(-d.im, d.re); }
+        case 8: {
+            const double a = 0.57735026918962576450914878050196, b = -1.1547005383792515290182975610039;
+            return mk(p.e[0][0].re * a + p.e[1][1].re * a + p.e[2][2].re * b, p.e[0][0].im * a + p.e[1][1].im * a + p.e[2][2].im * b);
+        }
+        default: return trace(p);
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fmunu(const double2* __restrict__ U, const Geom g, const int field, const int index1,
+                                                 const int index2, double2* __restrict__ partial, const int nblocks)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    double f[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) f[k] = 0.0;
+    if (t < 2 * g.vh_int) {
+        const int par = t / g.vh_int;
+        const Site x = site_of(g, t - par * g.vh_int, par);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int mu = field ? k : (k == 2 ? 1 : 0);
+            const int nu = field ? 3 : (k == 0 ? 1 : 2);
+            const su3 m1 = load_site_link<3>(U, g, mu, x);
+            const su3 m2 = load_site_link<3>(U, g, nu, fwd(g, x, mu));
+            const su3 m3 = herm(load_site_link<3>(U, g, mu, fwd(g, x, nu)));
+            const su3 m4 = herm(load_site_link<3>(U, g, nu, x));
+            const su3 p = mul(mul(mul(m1, m2), m3), m4);
+            const cplx t1 = trace_gell_mann(p, index1), t2 = trace_gell_mann(p, index2);
+            f[2 * k] = t1.im / 2;
+            f[2 * k + 1] = -t1.re / 2;
+            f[6 + 2 * k] = t2.im / 2;
+            f[6 + 2 * k + 1] = -t2.re / 2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        block_reduce_store<BLOCK>(f[2 * k], f[2 * k + 1], partial + (size_t)k * nblocks);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Profiles along a space axis (kernels lattice_action_diff_{x,y,z}, SU(N)/suncl/sun_measurements_cl.cl:186-616,
 // and lattice_polyakov_diff_{x,y,z}, SU(N)/suncl/polyakov.cl:142-402): the plaquette sums and the
 // Polyakov loops of the sites with coordinate b along `axis` (0 = x, 1 = y, 2 = z).  Workgroup

@@ -331,3 +331,27 @@ def test_cli_plane_resolved_observables(tmp_path):
             assert np.array_equal(sd3[name][key], sd[name][key])
         for key in pl[name]:
             assert np.array_equal(pl3[name][key], pl[name][key])
+
+
+def test_cli_fmunu_columns(tmp_path):
+    """FMUNU / F0MU with the FMUNU<k> index keys: the sixteen columns behind the Polyakov loop, on
+    the uncut lattice and cut into parts, against the checker (whose traces are pinned to the
+    reference's CPU code by the chk_su3 fixtures)."""
+    L = (6, 4, 4, 6)
+    keys = dict(GROUP=3, ND=4, L1=L[0], L2=L[1], L3=L[2], L4=L[3], BETA=5.8, NHIT=10, INTS=1, PRNG="RANLUX3",
+                RANDSERIES=54, NAV=0, ITER=3, NITER=1, PL_LEVEL=2, F0MU=1, FMUNU4=1, FMUNU7=1)
+    text, fields, rows, _ = _run(tmp_path / "a", keys)
+    _, _, rows2, _ = _run(tmp_path / "b", keys, "\tN1 = {2, 4}\n\tDEVICE = {0, 0}\n")
+    assert fields[10:14] == ["Fmunu_xt_4_re", "Fmunu_xt_4_im", "Fmunu_yt_4_re", "Fmunu_yt_4_im"]
+    assert fields[16:18] == ["Fmunu_xt_7_re", "Fmunu_xt_7_im"] and fields[22:26] == ["F0mu_abs_4_re", "F0mu_abs_4_im", "F0mu_abs_7_re", "F0mu_abs_7_im"]
+    assert " F0MU(4, 7)" in text and " Mean Fmunu_zt_7_im" in text
+    lat = ol.Lattice(3, L, 5.8, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE)
+    assert np.allclose(rows[0, 10:22], 0.0, atol=1e-15)            # cold start: every plaquette is the unit matrix
+    for i in (1, 2):
+        lat.sweep(1)
+        f = lat.fmunu_sums(1, 4, 7) / np.prod(L)
+        assert np.allclose(rows[i, 10:22], f, rtol=1e-10, atol=1e-14)
+        assert rows[i, 22] == pytest.approx(math.sqrt(f[0] ** 2 + f[2] ** 2 + f[4] ** 2), rel=1e-10)
+        assert rows[i, 25] == pytest.approx(math.sqrt(f[7] ** 2 + f[9] ** 2 + f[11] ** 2), rel=1e-10)
+    lat.close()
+    assert np.allclose(rows2, rows, rtol=1e-10, atol=1e-14)

@@ -311,3 +311,66 @@ def test_plane_profiles_match_checker(group, L):
         with pytest.raises(q.QcdError):
             c.plaquette_profile_sums(3)
     lat.close()
+
+
+def _check_cases():
+    import os
+    return sorted(f for f in os.listdir(ol.GOLDEN_DIR) if f.startswith("chk_su3_") and f.endswith(".json"))
+
+
+@pytest.mark.parametrize("fname", _check_cases())
+def test_observables_match_reference_cpu_remeasurement(fname):
+    """Plaquette, action, Polyakov loop, Wilson loop and the F_mu_nu traces of the fixture's
+    configuration against what the reference's own CPU code (su3cpu.cpp lattice_check_cpu) computed
+    for it; 1e-11 relative (different order of the sums)."""
+    import json
+    import os
+    import qcdgpu_amd as q
+    with open(os.path.join(ol.GOLDEN_DIR, fname)) as f:
+        doc = json.load(f)
+    table = np.load(os.path.join(ol.GOLDEN_DIR, doc["table"]), allow_pickle=False)
+    e = doc["expected"]
+    with q.Context(group=3, L=doc["L"], beta=doc["beta"]) as c:
+        c.upload(table)
+        plq, act, pol = c.plaquette(), c.action(), c.polyakov()
+        w = c.wilson_loop(doc["wilson_R"], doc["wilson_T"])
+        f = c.fmunu(doc["field"] - 1, doc["index1"], doc["index2"])
+        fs = c.fmunu(doc["field"] - 1, doc["index1"], doc["index2"], sums=True)
+        with pytest.raises(q.QcdError):
+            c.fmunu(2, 3, 8)
+    assert np.allclose(plq[:2], [e["Plq_spat"], e["Plq_temp"]], rtol=1e-12)
+    assert np.allclose(act[:2], [e["S_spat"], e["S_temp"]], rtol=1e-12)
+    assert np.allclose(pol, [e["Polyakov_loop"], e["Polyakov_loop_im"], e["Polyakov_loop_P2"], e["Polyakov_loop_P4"]],
+                       rtol=1e-11, atol=1e-14)
+    assert w == pytest.approx(e["Wilson_loop"], rel=1e-11)
+    want = np.array([e["F_%s_%s_%s" % (p, a, k)] for a in ("3", "8") for p in "abc" for k in ("re", "im")])
+    assert np.allclose(f, want, rtol=1e-10, atol=1e-14)
+    assert np.allclose(fs / np.prod(doc["L"]), f, rtol=1e-14)
+
+
+def _su2_check_cases():
+    import os
+    return sorted(f for f in os.listdir(ol.GOLDEN_DIR) if f.startswith("chk_su2_") and f.endswith(".json"))
+
+
+@pytest.mark.parametrize("fname", _su2_check_cases())
+def test_su2_observables_match_reference_cpu_remeasurement(fname):
+    """SU(2): the same against the reference's su2cpu.cpp; the F_mu_nu traces are SU(3) only here."""
+    import json
+    import os
+    import qcdgpu_amd as q
+    with open(os.path.join(ol.GOLDEN_DIR, fname)) as f:
+        doc = json.load(f)
+    table = np.load(os.path.join(ol.GOLDEN_DIR, doc["table"]), allow_pickle=False)
+    e = doc["expected"]
+    with q.Context(group=2, L=doc["L"], beta=doc["beta"]) as c:
+        c.upload(table)
+        plq, act, pol = c.plaquette(), c.action(), c.polyakov()
+        w = c.wilson_loop(doc["wilson_R"], doc["wilson_T"])
+        with pytest.raises(q.QcdError):
+            c.fmunu(0, 3, 8)
+    assert np.allclose(plq[:2], [e["Plq_spat"], e["Plq_temp"]], rtol=1e-12)
+    assert np.allclose(act[:2], [e["S_spat"], e["S_temp"]], rtol=1e-12)
+    assert np.allclose(pol, [e["Polyakov_loop"], e["Polyakov_loop_im"], e["Polyakov_loop_P2"], e["Polyakov_loop_P4"]],
+                       rtol=1e-11, atol=1e-14)
+    assert w == pytest.approx(e["Wilson_loop"], rel=1e-11)
