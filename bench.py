@@ -187,7 +187,10 @@ def main():
     # dominant kernel: k_update, V/2 link updates per launch; average launch duration from the
     # device-side event bracket around the timed sweeps (it contains nothing but those launches
     # on one GPU; with slabs it also contains the halo traffic, so the fraction is conservative)
-    per_launch_s = (ev_ms * 1e-3) / max(launches, 1)
+    # (a slab updates a pass in two launches, boundary slices first: count passes, not launches)
+    passes = 8 * args.steps
+    assert launches >= passes, (launches, passes)
+    per_launch_s = (ev_ms * 1e-3) / passes
     bytes_per_launch = BYTES_PER_LINK_UPDATE_SU3_F64 * sites_per_gpu / 2
     achieved = bytes_per_launch / per_launch_s / 1e9
     result = {

@@ -728,6 +728,13 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 #ifndef QCD_UPD_WAVES
 #define QCD_UPD_WAVES 2   // waves per SIMD the register budget is set for
 #endif
+// issue priority of a wave while it gathers the staple (mostly waiting for memory) and while it
+// generates random numbers and runs the heat-bath: the arithmetic phase goes first, so that the
+// wave sharing the SIMD spends its waiting time under it (measured: -1.5 % per pass)
+#ifndef QCD_PRIO_MEM
+#define QCD_PRIO_MEM 0
+#define QCD_PRIO_ALU 3
+#endif
 // everything an update launch needs, as ONE kernel argument: the kernel re-reads it from the
 // kernel-argument segment at the start of every trip of its loop (scalar loads), so that no
 // argument and nothing derived from one has to stay in registers from one site to the next
@@ -807,6 +814,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             // without a second round trip as soon as the staple's registers are free (requesting
             // state and link under the last staple term costs 40 registers and gains nothing)
             if (!GID) rs.attach(rv, t, rbuf + threadIdx.x);
+            __builtin_amdgcn_s_setprio(QCD_PRIO_MEM);
             StaplePipe sp;
             staple_pipe_head<DIR>(sp, U, g, hb, nbr, parity);
             raw_link own;
@@ -818,6 +826,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             QCD_STAMP(1);
             pin(own);
             Ul = as_su3(own);
+            __builtin_amdgcn_s_setprio(QCD_PRIO_ALU);
             if (!GID) rs.generate(r);
         } else {
             A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
