@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""profiles/roofline_traffic.json from a tools/collect_profiles.sh output directory: HBM bytes per
+k_update launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; the factor 2 on the read side is the
+gfx950 correction, checked in the same run on k_reunit, whose traffic is known exactly).
+
+usage: python3 tools/make_traffic_json.py gpurun_out/<dir> profiles/r01"""
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
+per = {}
+for k, v in pmc.items():
+    if "k_update<" in k and "redo" not in k:
+        per[k] = {"fetch_bytes": 2 * 1024.0 * v["FETCH_SIZE"]["mean_per_dispatch"],
+                  "write_bytes": 1024.0 * v["WRITE_SIZE"]["mean_per_dispatch"]}
+fetch = sum(p["fetch_bytes"] for p in per.values()) / len(per)
+write = sum(p["write_bytes"] for p in per.values()) / len(per)
+cal_f = json.load(open(os.path.join(src, "calib_fetch.json")))
+cal_w = json.load(open(os.path.join(src, "calib_write.json")))
+kf = [v for k, v in cal_f.items() if "k_reunit" in k][0]["FETCH_SIZE"]["mean_per_dispatch"]
+kw = [v for k, v in cal_w.items() if "k_reunit" in k][0]["WRITE_SIZE"]["mean_per_dispatch"]
+true_bytes = 402653184.0
+out = {
+    "hbm_bytes_per_update_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "per_kernel": per,
+    "source": "%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 3 "
+              "--warmup 1, 32^4 SU(3))" % dst,
+    "correction": "counters are in KiB; FETCH_SIZE doubled (gfx950 reports half the bytes of 16 B/lane streaming reads), WRITE_SIZE as is",
+    "calibration": {"kernel": "k_reunit 32^4 SU(3): reads %d B and writes %d B per launch" % (true_bytes, true_bytes),
+                    "FETCH_SIZE_KiB": kf, "WRITE_SIZE_KiB": kw,
+                    "fetch_ratio_reported_over_true": 1024.0 * kf / true_bytes,
+                    "write_ratio_reported_over_true": 1024.0 * kw / true_bytes},
+}
+json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), "roofline_traffic.json"), "w"), indent=1)
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "pmc_summary.json"))
+shutil.copy(os.path.join(src, "calib_fetch.json"), os.path.join(dst, "calib_reunit_fetch.json"))
+shutil.copy(os.path.join(src, "calib_write.json"), os.path.join(dst, "calib_reunit_write.json"))
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, "bench_under_rocprof.json"))
+for f in os.listdir(os.path.join(src, "stats")):
+    if f.endswith("kernel_stats.csv"):
+        shutil.copy(os.path.join(src, "stats", f), os.path.join(dst, "kernel_stats_bench_32x4.csv"))
+print(json.dumps({k: out[k] for k in ("hbm_bytes_per_update_launch", "fetch_bytes", "write_bytes")}), out["calibration"])
