@@ -124,9 +124,10 @@ int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
  * kernel lattice_measurement_plq, sun_measurements_cl.cl:712-1175; CPU twin su3cpu.cpp:1212-1381):
  * F_re = Im Tr(P lambda_a)/2, F_im = -Re Tr(P lambda_a)/2 of the plaquette matrix P, per plane.
  * field 0 = planes xy, xz, yz (FMUNU, "H field"), 1 = xt, yt, zt (F0MU, "E field"); index1 in
- * {1,2,3,4}, index2 in {5,6,7,8} in the reference (FMUNU1.. keys), any 1..8 here.  out = for
+ * {1,2,3,4}, index2 in {5,6,7,8} in the reference (FMUNU1.. keys), any 1..8 here; SU(2): Pauli
+ * matrices 1..3 (the reference: index1 3 or 1, index2 2; su2cpu.cpp:716-870).  out = for
  * (index1, index2) x three planes x (re, im).  qcd_measure_fmunu: averages over this context's
- * sites; _sums: raw sums (slabs: add over contexts, divide by the full volume).  SU(3) only. */
+ * sites; _sums: raw sums (slabs: add over contexts, divide by the full volume). */
 int qcd_measure_fmunu(qcd_ctx *ctx, int field, int index1, int index2, double out[12]);
 int qcd_measure_fmunu_sums(qcd_ctx *ctx, int field, int index1, int index2, double sums[12]);
 

@@ -31,9 +31,9 @@ CASES = {
     "4x6x4x6_E15": dict(L=(4, 6, 4, 6), beta=5.6, nhit=6, sweeps=2, field=2, idx=(1, 5), wilson=(2, 3)),
     "6x4x4x4_H47": dict(L=(6, 4, 4, 4), beta=2.0, nhit=4, sweeps=2, field=1, idx=(4, 7), wilson=(2, 2)),
     "4x4x6x4_E26": dict(L=(4, 4, 6, 4), beta=6.2, nhit=10, sweeps=4, field=2, idx=(2, 6), wilson=(3, 1)),
-    # SU(2): plaquettes, Wilson loop and Polyakov loop (the F columns of the SU(2) twin are not used)
-    "su2_4x4x4x6": dict(group=2, L=(4, 4, 4, 6), beta=2.3, nhit=6, sweeps=3, field=0, idx=(3, 8), wilson=(2, 2)),
-    "su2_6x4x4x4": dict(group=2, L=(6, 4, 4, 4), beta=1.5, nhit=4, sweeps=2, field=0, idx=(3, 8), wilson=(1, 3)),
+    # SU(2): Pauli matrices, index1 3 or 1, index2 2 (SU(N)/suncl/suncl.cpp:2094-2101)
+    "su2_4x4x4x6": dict(group=2, L=(4, 4, 4, 6), beta=2.3, nhit=6, sweeps=3, field=1, idx=(3, 2), wilson=(2, 2)),
+    "su2_6x4x4x4": dict(group=2, L=(6, 4, 4, 4), beta=1.5, nhit=4, sweeps=2, field=2, idx=(1, 2), wilson=(1, 3)),
 }
 
 

@@ -1022,7 +1022,7 @@ void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out)
  * P = U_mu(x) U_nu(x+mu) U_mu(x+nu)^+ U_nu(x)^+ times the Gell-Mann matrix lambda_a,
  * F_re = Im Tr(P lambda_a) / 2, F_im = -Re Tr(P lambda_a) / 2, summed over the sites.
  * field 0: planes xy, xz, yz (get_Fmunu); field 1: planes xt, yt, zt (get_F0mu).
- * out[4*0 .. ] layout: for a in (index1, index2), for the three planes: (re, im).  SU(3) only. */
+ * out layout: for a in (index1, index2), for the three planes: (re, im). */
 static qo_su3 gell_mann(int index)
 {
     /* su3cpu.cpp:775-920 */
@@ -1053,7 +1053,33 @@ void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, dou
     const qo_su3 l1 = gell_mann(index1), l2 = gell_mann(index2);
     static const int planes[2][3][2] = { { {0, 1}, {0, 2}, {1, 2} }, { {0, 3}, {1, 3}, {2, 3} } };
     for (int i = 0; i < 12; i++) out[i] = 0.0;
-    if (lat->group != 3) return;
+    if (lat->group != 3) {
+        /* SU(2): Pauli matrices, SU(N)/suncl/su2cpu.cpp:496-545, 716-870 */
+        const qo_su2 *t2 = (const qo_su2 *)lat->links;
+        qo_su2 s[2];
+        const int idx[2] = { index1, index2 };
+        for (int a = 0; a < 2; a++) {
+            memset(&s[a], 0, sizeof(qo_su2));
+            if (idx[a] == 1) { s[a].u2.re = 1.0; s[a].v1.re = 1.0; }
+            else if (idx[a] == 2) { s[a].u2.im = -1.0; s[a].v1.im = 1.0; }
+            else { s[a].u1.re = 1.0; s[a].v2.re = -1.0; }
+        }
+        for (int gid = 0; gid < lat->sites; gid++)
+            for (int k = 0; k < 3; k++) {
+                const int dir = planes[field][k][0], dir1 = planes[field][k][1];
+                int g1 = qo_neighbour(lat->L, gid, dir);
+                int g2 = qo_neighbour(lat->L, gid, dir1);
+                qo_su2 m1 = t2[gid * nd + dir], m2 = t2[g1 * nd + dir1];
+                qo_su2 m3 = qo_herm2(&t2[g2 * nd + dir]), m4 = qo_herm2(&t2[gid * nd + dir1]);
+                qo_su2 p = qo_mul2(&m1, &m2); p = qo_mul2(&p, &m3); p = qo_mul2(&p, &m4);
+                for (int a = 0; a < 2; a++) {
+                    qo_su2 t = qo_mul2(&p, &s[a]);
+                    out[6 * a + 2 * k] += (t.u1.im + t.v2.im) / 2;
+                    out[6 * a + 2 * k + 1] += -(t.u1.re + t.v2.re) / 2;
+                }
+            }
+        return;
+    }
     for (int gid = 0; gid < lat->sites; gid++)
         for (int k = 0; k < 3; k++) {
             const int dir = planes[field][k][0], dir1 = planes[field][k][1];

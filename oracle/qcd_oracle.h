@@ -12,7 +12,7 @@
  * modes.  The Polyakov loop, the Wilson loop and the F_mu_nu traces are pinned
  * against the reference's CPU re-measurement of a configuration
  * (SU(N)/suncl/su3cpu.cpp:1616-1704, compiled into oracle/_ref/qcdgpu_sun_check by
- * `make ref_sun`; fixtures tests/golden/chk_su3_*, chk_su2_*; the F traces for SU(3) only);
+ * `make ref_sun`; fixtures tests/golden/chk_su3_*, chk_su2_*);
  * the hot start, the overrelaxation and the plane profiles are "parity unpinned".
  */
 #ifndef QCD_ORACLE_H
@@ -131,7 +131,7 @@ void qo_polyakov(const qo_lattice *lat, double out[4]);
 void qo_plaquette_profile_sums(const qo_lattice *lat, int axis, double *out);
 void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out);
 
-/* F_mu_nu traces summed over the sites, SU(3): field 0 = planes xy,xz,yz, 1 = xt,yt,zt; out = for
+/* F_mu_nu traces summed over the sites (Gell-Mann matrices 1..8 for SU(3), Pauli 1..3 for SU(2)): field 0 = planes xy,xz,yz, 1 = xt,yt,zt; out = for
  * (index1, index2) x three planes x (re, im); SU(N)/suncl/su3cpu.cpp:1212-1381 */
 void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, double out[12]);
 

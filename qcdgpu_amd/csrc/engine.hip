@@ -734,14 +734,19 @@ int qcd_measure_fmunu_sums(qcd_ctx* c, int field, int index1, int index2, double
 {
     int rc = check_ctx(c, true);
     if (rc) return rc;
-    if (c->p.group != 3) return fail(QCD_ERR_UNSUPPORTED, "the F_mu_nu traces are implemented for SU(3) only");
     if (field != 0 && field != 1) return fail(QCD_ERR_INVALID, "field %d is not 0 (xy, xz, yz) or 1 (xt, yt, zt)", field);
-    if (index1 < 1 || index1 > 8 || index2 < 1 || index2 > 8) return fail(QCD_ERR_INVALID, "Gell-Mann indices %d, %d outside 1..8", index1, index2);
+    const int top = c->p.group == 3 ? 8 : 3;   // Gell-Mann or Pauli matrices
+    if (index1 < 1 || index1 > top || index2 < 1 || index2 > top)
+        return fail(QCD_ERR_INVALID, "generator indices %d, %d outside 1..%d", index1, index2, top);
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     if (6L * c->npartial > c->partial_len) return fail(QCD_ERR_UNSUPPORTED, "reduction buffer too small");
     Timed tm(c, 1);
-    hipLaunchKernelGGL((k_fmunu<MEAS_BLOCK>), dim3(c->npartial), dim3(MEAS_BLOCK), 0, c->stream, c->U, c->g, field, index1, index2,
-                       c->partial, c->npartial);
+    if (c->p.group == 3)
+        hipLaunchKernelGGL((k_fmunu<3, MEAS_BLOCK>), dim3(c->npartial), dim3(MEAS_BLOCK), 0, c->stream, c->U, c->g, field, index1,
+                           index2, c->partial, c->npartial);
+    else
+        hipLaunchKernelGGL((k_fmunu<2, MEAS_BLOCK>), dim3(c->npartial), dim3(MEAS_BLOCK), 0, c->stream, c->U, c->g, field, index1,
+                           index2, c->partial, c->npartial);
     HIP_TRY(hipGetLastError());
     rc = reduce_partials(c, c->npartial, 6, sums);
     if (rc) return rc;

@@ -267,7 +267,11 @@ void model::lattice_init(void)
     if (lattice_nd != 4) throw model_error("ND must be 4");
     if (precision != model_precision_double) throw model_error("only double precision is implemented");
     if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
-    if ((get_Fmunu || get_F0mu) && lattice_group != 3) throw model_error("FMUNU / F0MU are implemented for SU(3) only");
+    if ((get_Fmunu || get_F0mu) && lattice_group == 2) {
+        // Fmunu_defaults, SU(N)/suncl/suncl.cpp:2094-2101: Pauli matrices, first index 3 or 1, second 2
+        Fmunu_index1 = Fmunu_index1 == 1 ? 1 : 3;
+        Fmunu_index2 = 2;
+    }
     if (get_wilson_loop && lattice_Nparts > 1) throw model_error("the Wilson loop is measured on an uncut lattice only (GETWILSON with N1 = {..})");
     // initialize_CPU (SU(N)/random/random.cpp:174-182): RANDSERIES = 0 means "seed from the clock"
     PRNG0->PRNG_srandtime = (unsigned int)time(NULL);

@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(BLOCK) void k_polyakov(const double2* __restrict__ 
 // lattice_retrace_plaquette3_F, SU(N)/suncl/su3_measurements_cl.cl:550-589; CPU twin
 // SU(N)/suncl/su3cpu.cpp:1212-1381): per site and plane the plaquette matrix
 // P = U_mu(x) U_nu(x+mu) U_mu(x+nu)^+ U_nu(x)^+ and  F_re = Im Tr(P lambda_a) / 2,
-// F_im = -Re Tr(P lambda_a) / 2  for two Gell-Mann matrices.  field 0: planes xy, xz, yz; field 1:
+// F_im = -Re Tr(P lambda_a) / 2  for two Gell-Mann (SU(3)) or Pauli (SU(2)) matrices.  field 0: planes xy, xz, yz; field 1:
 // planes xt, yt, zt.  partial[(3 * a + plane) * nblocks + block] = (sum F_re, sum F_im).
 
 // Tr(P lambda_index), Gell-Mann matrices as su3cpu.cpp:775-920 writes them
@@ -1185,7 +1185,18 @@ __device__ __forceinline__ cplx trace_gell_mann(const su3& p, int index)
     }
 }
 
-template <int BLOCK>
+// Tr(P sigma_index), Pauli matrices (SU(N)/suncl/su2cpu.cpp:496-545; index 1..3)
+__device__ __forceinline__ cplx trace_gell_mann(const su2& p, int index)
+{
+    switch (index) {
+        case 1: return cadd(p.e[0][1], p.e[1][0]);
+        case 2: { const cplx d = csub(p.e[0][1], p.e[1][0]); return mk(-d.im, d.re); }
+        case 3: return csub(p.e[0][0], p.e[1][1]);
+        default: return trace(p);
+    }
+}
+
+template <int GROUP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fmunu(const double2* __restrict__ U, const Geom g, const int field, const int index1,
                                                  const int index2, double2* __restrict__ partial, const int nblocks)
 {
@@ -1200,11 +1211,11 @@ __global__ __launch_bounds__(BLOCK) void k_fmunu(const double2* __restrict__ U, 
         for (int k = 0; k < 3; k++) {
             const int mu = field ? k : (k == 2 ? 1 : 0);
             const int nu = field ? 3 : (k == 0 ? 1 : 2);
-            const su3 m1 = load_site_link<3>(U, g, mu, x);
-            const su3 m2 = load_site_link<3>(U, g, nu, fwd(g, x, mu));
-            const su3 m3 = herm(load_site_link<3>(U, g, mu, fwd(g, x, nu)));
-            const su3 m4 = herm(load_site_link<3>(U, g, nu, x));
-            const su3 p = mul(mul(mul(m1, m2), m3), m4);
+            const mat<GROUP> m1 = load_site_link<GROUP>(U, g, mu, x);
+            const mat<GROUP> m2 = load_site_link<GROUP>(U, g, nu, fwd(g, x, mu));
+            const mat<GROUP> m3 = herm(load_site_link<GROUP>(U, g, mu, fwd(g, x, nu)));
+            const mat<GROUP> m4 = herm(load_site_link<GROUP>(U, g, nu, x));
+            const mat<GROUP> p = mul(mul(mul(m1, m2), m3), m4);
             const cplx t1 = trace_gell_mann(p, index1), t2 = trace_gell_mann(p, index2);
             f[2 * k] = t1.im / 2;
             f[2 * k + 1] = -t1.re / 2;

@@ -355,7 +355,7 @@ def _su2_check_cases():
 
 @pytest.mark.parametrize("fname", _su2_check_cases())
 def test_su2_observables_match_reference_cpu_remeasurement(fname):
-    """SU(2): the same against the reference's su2cpu.cpp; the F_mu_nu traces are SU(3) only here."""
+    """SU(2): the same against the reference's su2cpu.cpp (F_mu_nu with Pauli matrices)."""
     import json
     import os
     import qcdgpu_amd as q
@@ -367,10 +367,13 @@ def test_su2_observables_match_reference_cpu_remeasurement(fname):
         c.upload(table)
         plq, act, pol = c.plaquette(), c.action(), c.polyakov()
         w = c.wilson_loop(doc["wilson_R"], doc["wilson_T"])
+        f = c.fmunu(doc["field"] - 1, doc["index1"], doc["index2"])
         with pytest.raises(q.QcdError):
-            c.fmunu(0, 3, 8)
+            c.fmunu(0, 3, 8)          # SU(2) has three generators
     assert np.allclose(plq[:2], [e["Plq_spat"], e["Plq_temp"]], rtol=1e-12)
     assert np.allclose(act[:2], [e["S_spat"], e["S_temp"]], rtol=1e-12)
     assert np.allclose(pol, [e["Polyakov_loop"], e["Polyakov_loop_im"], e["Polyakov_loop_P2"], e["Polyakov_loop_P4"]],
                        rtol=1e-11, atol=1e-14)
     assert w == pytest.approx(e["Wilson_loop"], rel=1e-11)
+    want = np.array([e["F_%s_%s_%s" % (p, a, k)] for a in ("3", "8") for p in "abc" for k in ("re", "im")])
+    assert np.allclose(f, want, rtol=1e-10, atol=1e-14)

@@ -287,8 +287,8 @@ SU2_CHK_CASES = sorted(f for f in os.listdir(ol.GOLDEN_DIR) if f.startswith("chk
 
 @pytest.mark.parametrize("fname", SU2_CHK_CASES)
 def test_su2_polyakov_wilson_match_reference_cpu_code(fname):
-    """SU(2): plaquettes, action, Polyakov loop and Wilson loop against the reference's SU(2) CPU
-    re-measurement (SU(N)/suncl/su2cpu.cpp lattice_check_cpu)."""
+    """SU(2): plaquettes, action, Polyakov loop, Wilson loop and the F_mu_nu traces (Pauli matrices)
+    against the reference's SU(2) CPU re-measurement (SU(N)/suncl/su2cpu.cpp lattice_check_cpu)."""
     doc, table = load_check_case(fname)
     e = doc["expected"]
     lat = ol.Lattice(2, doc["L"], doc["beta"], nhit=1, ints=1, rng_mode=ol.RNG_PERSITE)
@@ -299,4 +299,6 @@ def test_su2_polyakov_wilson_match_reference_cpu_code(fname):
     want = [e["Polyakov_loop"], e["Polyakov_loop_im"], e["Polyakov_loop_P2"], e["Polyakov_loop_P4"]]
     assert np.allclose(pol, want, rtol=1e-12, atol=1e-15)
     assert lat.wilson_loop(doc["wilson_R"], doc["wilson_T"]) == pytest.approx(e["Wilson_loop"], rel=1e-12)
+    f = lat.fmunu_sums(doc["field"] - 1, doc["index1"], doc["index2"]) / np.prod(doc["L"])
+    assert np.allclose(f, expected_fmunu(doc), rtol=1e-11, atol=1e-15)
     lat.close()
