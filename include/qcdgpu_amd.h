@@ -98,6 +98,15 @@ int qcd_sweep(qcd_ctx *ctx, int n);
  * interior is being updated.  The ranges of one pass must tile the slab exactly once. */
 int qcd_update_range(qcd_ctx *ctx, int parity, int dir, int xs_begin, int xs_count);
 
+/* One pass in two concurrent launches: the owned slices [first_begin, first_begin + first_count)
+ * (wrapping) on the context's stream, all the others on a stream of the context's own beside them.
+ * Calls that follow on the context's stream are ordered after the FIRST part only as long as they
+ * are halo calls (qcd_halo_pack / _unpack / _copy); every other entry point waits for the rest as
+ * well.  So a slab updates its boundary slices, packs and sends them while the interior is still
+ * being updated, without the two launches having to run one after the other.  No counterpart in
+ * the reference (see qcd_update_range). */
+int qcd_update_split(qcd_ctx *ctx, int parity, int dir, int first_begin, int first_count);
+
 /* Overrelaxation (microcanonical reflection in the three SU(2) subgroups, same pass structure
  * and halo rule as qcd_update).  The reference has no overrelaxation: no call site to replace,
  * and no reference output to pin it to -- it is checked by the invariance of the action. */

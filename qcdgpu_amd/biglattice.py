@@ -147,6 +147,9 @@ class GpuSlabEngine:
     def update_range(self, parity, direction, xs_begin, xs_count):
         self.ctx.update_range(parity, direction, xs_begin, xs_count)
 
+    def update_split(self, parity, direction, first_begin, first_count):
+        self.ctx.update_split(parity, direction, first_begin, first_count)
+
     @property
     def nx(self):
         return self.ctx.params.nx_local
@@ -193,22 +196,30 @@ class BigLattice:
             for parity in (0, 1):
                 self.comm.exchange(d, parity)
 
-    # x-slices on either side of a slab that are updated ahead of the rest (at most a quarter of
-    # the slab per side); only the outermost slice travels, the others give the first launch
-    # enough work to keep the device busy.  Measured on one MI355X, 32^4 slab, messages copied
-    # device to device: 186 us per pass unsplit, 203 us split 8 deep (210 us 2 or 4 deep) -- the
-    # split costs 17 us of launch ramp and tail and takes the whole message time off the
-    # critical path, which over xGMI is the larger of the two.
+    # A pass is split so that a slab's boundary slices are updated, packed and sent while its
+    # interior is still being updated (sites of one pass do not read each other's links, so the
+    # order inside a pass is free).  Engines with update_split run the two parts as concurrent
+    # launches (the boundary part on the stream the halo calls follow, the rest beside it): one
+    # slice per side is enough then.  Engines with update_range only run them one after the other,
+    # and the first launch gets more slices (at most a quarter of the slab per side) so that it
+    # keeps the device busy.  Measured on one MI355X, 32^4 slab, messages copied device to device:
+    # 179 us per pass unsplit, 204 us split into consecutive launches 8 deep, 191 us as two
+    # concurrent launches with one slice per side.
     BOUNDARY_DEPTH = 8
+    BOUNDARY_DEPTH_CONCURRENT = 1
+
+    def _concurrent(self) -> bool:
+        return all(hasattr(e, "update_split") for e in self.engines)
 
     def boundary_depth(self) -> int:
         """Slices per side updated first, or 0 to update the slab in one launch."""
-        if not all(hasattr(e, "update_range") and hasattr(e, "nx") for e in self.engines):
+        if not all((hasattr(e, "update_range") or hasattr(e, "update_split")) and hasattr(e, "nx") for e in self.engines):
             return 0
         if not hasattr(self.comm, "start_exchange"):
             return 0
         nx = min(e.nx for e in self.engines)
-        depth = min(self.BOUNDARY_DEPTH, nx // 4)
+        want = self.BOUNDARY_DEPTH_CONCURRENT if self._concurrent() else self.BOUNDARY_DEPTH
+        depth = min(want, nx // 4)
         return depth if depth >= 1 else 0
 
     def update(self, parity: int, direction: int):
@@ -218,14 +229,18 @@ class BigLattice:
                 e.update(parity, direction)
             self.comm.exchange(direction, parity)
             return
-        # sites of one pass do not read each other's links, so the order inside a pass is free:
-        # the `depth` slices next to either face first (one launch, wrapping around the slab),
-        # their outermost slices go on the wire, the interior is updated meanwhile
-        for e in self.engines:
-            e.update_range(parity, direction, e.nx - depth, 2 * depth)
-        pending = self.comm.start_exchange(direction, parity)
-        for e in self.engines:
-            e.update_range(parity, direction, depth, e.nx - 2 * depth)
+        # the `depth` slices next to either face first (one range, wrapping around the slab), their
+        # outermost slices go on the wire, the interior is updated meanwhile
+        if self._concurrent():
+            for e in self.engines:
+                e.update_split(parity, direction, e.nx - depth, 2 * depth)
+            pending = self.comm.start_exchange(direction, parity)
+        else:
+            for e in self.engines:
+                e.update_range(parity, direction, e.nx - depth, 2 * depth)
+            pending = self.comm.start_exchange(direction, parity)
+            for e in self.engines:
+                e.update_range(parity, direction, depth, e.nx - 2 * depth)
         self.comm.finish_exchange(direction, parity, pending)
 
     def overrelax_sweep(self, n: int = 1):
@@ -302,6 +317,9 @@ class LocalGpuEngine:
 
     def update_range(self, parity, direction, xs_begin, xs_count):
         self.ctx.update_range(parity, direction, xs_begin, xs_count)
+
+    def update_split(self, parity, direction, first_begin, first_count):
+        self.ctx.update_split(parity, direction, first_begin, first_count)
 
     @property
     def nx(self):

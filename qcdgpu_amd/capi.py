@@ -51,7 +51,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
            "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
            "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range",
-           "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
+           "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
            "qcd_on_download"]
@@ -105,6 +105,7 @@ def _load():
     lib.qcd_math_check.argtypes = [I, I, C.POINTER(C.c_double)]
     lib.qcd_overrelax.argtypes = [P, I, I]
     lib.qcd_update_range.argtypes = [P, I, I, I, I]
+    lib.qcd_update_split.argtypes = [P, I, I, I, I]
     lib.qcd_measure_wilson.argtypes = [P, I, I, C.POINTER(C.c_double)]
     lib.qcd_overrelax_sweep.argtypes = [P, I]
     lib.qcd_rng_state_bytes.restype = C.c_size_t
@@ -254,6 +255,10 @@ class Context:
 
     def update_range(self, parity, direction, xs_begin, xs_count):
         _check(lib.qcd_update_range(self.h, parity, direction, xs_begin, xs_count))
+
+    def update_split(self, parity, direction, first_begin, first_count):
+        """One pass: slices [first_begin, +first_count) on the context's stream, the rest beside them."""
+        _check(lib.qcd_update_split(self.h, parity, direction, first_begin, first_count))
 
     def wilson_loop(self, R, T):
         out = C.c_double()

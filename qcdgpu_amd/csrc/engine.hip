@@ -87,8 +87,15 @@ struct qcd_ctx {
     unsigned long long* draws_dev;
     unsigned long long* draws_host;  // pinned
     int* redo_list;           // update pass: sites left to the general random stream
-    unsigned* redo_count;     // two counters, used by alternate passes
+    unsigned* redo_count;     // two counters, used by alternate passes (a second pair for the side lane)
     unsigned pass_no;
+    // side lane of qcd_update_split: the rest of a pass runs on its own stream, next to the
+    // boundary part on the context's stream
+    hipStream_t side_stream;
+    hipEvent_t fork_ev, join_ev;
+    bool side_pending;        // the context's stream has not yet waited for the side lane's last launch
+    int* redo_list_side;
+    unsigned pass_no_side;
     bool initialized;
     bool profiling;
     hipEvent_t ev0, ev1;
@@ -133,8 +140,9 @@ struct Timed {
 // NSKIP: 223 = RANLUX3 (the reference's default, QCDGPU.cpp:98) with the skip unrolled at compile
 // time; 0 = any luxury level, skip count at run time
 template <int GROUP, bool GID, int NSKIP>
-int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count)
+int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count, bool side = false)
 {
+    hipStream_t stream = side ? c->side_stream : c->stream;
     Geom g = c->g;
     g.ux0 = xs_begin;
     g.unx = xs_count;
@@ -158,12 +166,15 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
-    a.redo_list = c->redo_list;
-    a.redo_count = c->redo_count + (c->pass_no & 1u);
-    a.redo_count_next = c->redo_count + ((c->pass_no + 1u) & 1u);
-    c->pass_no++;
+    // each lane has its own list and counter pair: its launches are ordered, the lanes are not
+    unsigned& pass_no = side ? c->pass_no_side : c->pass_no;
+    unsigned* counts = c->redo_count + (side ? 2 : 0);
+    a.redo_list = side ? c->redo_list_side : c->redo_list;
+    a.redo_count = counts + (pass_no & 1u);
+    a.redo_count_next = counts + ((pass_no + 1u) & 1u);
+    pass_no++;
 #define QCD_LAUNCH_UPDATE(D) \
-    hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, c->stream, a)
+    hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, stream, a)
     switch (dir) {
         case 0: QCD_LAUNCH_UPDATE(0); break;
         case 1: QCD_LAUNCH_UPDATE(1); break;
@@ -175,7 +186,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
         // the few sites (none at large beta) whose random window ran dry; also re-arms the list
         const dim3 rgrid(REDO_GRID), rblock(REDO_BLOCK);
 #define QCD_LAUNCH_REDO(D) \
-    hipLaunchKernelGGL((k_update_redo<GROUP, D, REDO_BLOCK, UPD_BLOCK>), rgrid, rblock, 0, c->stream, a)
+    hipLaunchKernelGGL((k_update_redo<GROUP, D, REDO_BLOCK, UPD_BLOCK>), rgrid, rblock, 0, stream, a)
         switch (dir) {
             case 0: QCD_LAUNCH_REDO(0); break;
             case 1: QCD_LAUNCH_REDO(1); break;
@@ -201,19 +212,19 @@ int launch_overrelax(qcd_ctx* c, int parity, int dir)
     return QCD_OK;
 }
 
-int launch_update(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count)
+int launch_update(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count, bool side = false)
 {
     const bool gid = (c->p.start_mode == QCD_START_GID);
     const bool lux3 = (c->p.lux_level == 3);
     Timed tm(c, 0);
     if (c->p.group == 3) {
-        if (gid) launch_update_dir<3, true, 0>(c, parity, dir, xs_begin, xs_count);
-        else if (lux3) launch_update_dir<3, false, 223>(c, parity, dir, xs_begin, xs_count);
-        else launch_update_dir<3, false, 0>(c, parity, dir, xs_begin, xs_count);
+        if (gid) launch_update_dir<3, true, 0>(c, parity, dir, xs_begin, xs_count, side);
+        else if (lux3) launch_update_dir<3, false, 223>(c, parity, dir, xs_begin, xs_count, side);
+        else launch_update_dir<3, false, 0>(c, parity, dir, xs_begin, xs_count, side);
     } else {
-        if (gid) launch_update_dir<2, true, 0>(c, parity, dir, xs_begin, xs_count);
-        else if (lux3) launch_update_dir<2, false, 223>(c, parity, dir, xs_begin, xs_count);
-        else launch_update_dir<2, false, 0>(c, parity, dir, xs_begin, xs_count);
+        if (gid) launch_update_dir<2, true, 0>(c, parity, dir, xs_begin, xs_count, side);
+        else if (lux3) launch_update_dir<2, false, 223>(c, parity, dir, xs_begin, xs_count, side);
+        else launch_update_dir<2, false, 0>(c, parity, dir, xs_begin, xs_count, side);
     }
     return tm.finish();
 }
@@ -353,11 +364,18 @@ int seed_streams(qcd_ctx* c)
     return QCD_OK;
 }
 
-int check_ctx(const qcd_ctx* c, bool need_init)
+// join = false: the call may run beside the side lane of qcd_update_split (halo messages only)
+int check_ctx(qcd_ctx* c, bool need_init, bool join = true)
 {
     if (!c) return fail(QCD_ERR_INVALID, "null context");
     if (need_init && !c->initialized) return fail(QCD_ERR_STATE, "lattice not initialised: call qcd_init_lattice or qcd_upload first");
-    return set_device(c);
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (join && c->side_pending) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
+        c->side_pending = false;
+    }
+    return QCD_OK;
 }
 
 int reduce_partials(qcd_ctx* c, int n, int nout, double* host_out)
@@ -500,8 +518,14 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double)), "hipHostMalloc(result)");
     tryhip(hipMalloc(&c->draws_dev, sizeof(unsigned long long)), "hipMalloc(draws)");
     tryhip(hipMalloc(&c->redo_list, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list)");
-    tryhip(hipMalloc(&c->redo_count, 2 * sizeof(unsigned)), "hipMalloc(redo count)");
-    if (rc == QCD_OK) tryhip(hipMemset(c->redo_count, 0, 2 * sizeof(unsigned)), "hipMemset(redo count)");
+    tryhip(hipMalloc(&c->redo_count, 4 * sizeof(unsigned)), "hipMalloc(redo count)");
+    if (rc == QCD_OK) tryhip(hipMemset(c->redo_count, 0, 4 * sizeof(unsigned)), "hipMemset(redo count)");
+    if (g.halo) {   // slabs only: the side lane of qcd_update_split
+        tryhip(hipMalloc(&c->redo_list_side, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list, side lane)");
+        tryhip(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "hipStreamCreate(side lane)");
+        tryhip(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming), "hipEventCreate");
+        tryhip(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming), "hipEventCreate");
+    }
     tryhip(hipHostMalloc(&c->draws_host, sizeof(unsigned long long)), "hipHostMalloc(draws)");
     if (rc != QCD_OK) {
         qcd_destroy(c);
@@ -527,6 +551,13 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipFree(c->draws_dev);
     (void)hipFree(c->redo_list);
     (void)hipFree(c->redo_count);
+    (void)hipFree(c->redo_list_side);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->result_host) (void)hipHostFree(c->result_host);
     if (c->draws_host) (void)hipHostFree(c->draws_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -620,6 +651,34 @@ int qcd_update_range(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count
     if (xs_begin < 0 || xs_begin >= c->g.nx || xs_count < 1 || xs_count > c->g.nx)
         return fail(QCD_ERR_INVALID, "slice range %d + %d of %d owned slices", xs_begin, xs_count, c->g.nx);
     return launch_update(c, parity, dir, xs_begin, xs_count);
+}
+
+int qcd_update_split(qcd_ctx* c, int parity, int dir, int first_begin, int first_count)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    const int nx = c->g.nx;
+    if (first_begin < 0 || first_begin >= nx || first_count < 1 || first_count > nx)
+        return fail(QCD_ERR_INVALID, "slice range %d + %d of %d owned slices", first_begin, first_count, nx);
+    if (first_count == nx) return launch_update(c, parity, dir, first_begin, first_count);
+    const int rest_begin = (first_begin + first_count) % nx, rest_count = nx - first_count;
+    if (!c->side_stream || c->profiling) {
+        // no side lane (a context without halos), or per-launch timing asked for: one after the other
+        rc = launch_update(c, parity, dir, first_begin, first_count);
+        return rc ? rc : launch_update(c, parity, dir, rest_begin, rest_count);
+    }
+    // the rest of the pass needs everything issued so far, but not the first part
+    HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
+    rc = launch_update(c, parity, dir, first_begin, first_count);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(c->side_stream, c->fork_ev, 0));
+    rc = launch_update(c, parity, dir, rest_begin, rest_count, true);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->join_ev, c->side_stream));
+    c->side_pending = true;
+    return QCD_OK;
 }
 
 int qcd_overrelax(qcd_ctx* c, int parity, int dir)
@@ -918,7 +977,7 @@ size_t qcd_halo_bytes(const qcd_ctx* c)
 
 static int halo_op(qcd_ctx* c, int side, int dir, int parity, void* buf, bool pack)
 {
-    int rc = check_ctx(c, true);
+    int rc = check_ctx(c, true, false);
     if (rc) return rc;
     if (!c->g.halo) return fail(QCD_ERR_STATE, "context has no halo slices");
     if (side != 0 && side != 1) return fail(QCD_ERR_INVALID, "side %d", side);

@@ -47,6 +47,12 @@ class CpuSlabEngine:
         if xs_count > first:
             ol.lib.qo_update_pass_range(self.lat.h, parity, direction, self.x0, self.x0 + xs_count - first)
 
+    def update_split(self, parity, direction, first_begin, first_count):
+        # the device engine runs the two parts as concurrent launches; the order does not matter
+        self.update_range(parity, direction, first_begin, first_count)
+        if first_count < self.nx:
+            self.update_range(parity, direction, (first_begin + first_count) % self.nx, self.nx - first_count)
+
     def _sel(self, x, parity):
         return ((self.yzt_parity + x) & 1) == parity
 

@@ -206,16 +206,20 @@ def test_biglattice_python_driver_on_one_gpu():
         lat.close()
 
 
-def test_biglattice_boundary_first_update_on_one_gpu():
-    """Slabs wide enough for the split pass: boundary slices (two deep here), halo messages,
-    then the interior -- same configuration as the uncut lattice, and the range entry point
-    rejects ranges outside the slab."""
+@pytest.mark.parametrize("beta,nhit,concurrent", [(5.8, 4, True), (1.0, 12, True), (5.8, 4, False)])
+def test_biglattice_boundary_first_update_on_one_gpu(beta, nhit, concurrent, monkeypatch):
+    """Slabs wide enough for the split pass: boundary slices, halo messages, interior -- as two
+    concurrent launches (qcd_update_split; the low-beta case keeps both lanes' redo lists busy) or
+    one after the other (qcd_update_range).  Same configuration as the uncut lattice; the entry
+    points reject ranges outside the slab."""
     import qcdgpu_amd as q
     from qcdgpu_amd import biglattice as bl
     L = (16, 4, 4, 6)
-    lat = ol.Lattice(3, L, 5.8, nhit=4, ints=1, rng_mode=ol.RNG_PERSITE, seed=29)
-    big = bl.make_gpu_slabs(3, L, 5.8, [8, 8], nhit=4, rand_series=29)
-    assert big.boundary_depth() == 2                 # a quarter of the narrowest slab
+    lat = ol.Lattice(3, L, beta, nhit=nhit, ints=1, rng_mode=ol.RNG_PERSITE, seed=29)
+    big = bl.make_gpu_slabs(3, L, beta, [8, 8], nhit=nhit, rand_series=29)
+    if not concurrent:
+        monkeypatch.setattr(bl.BigLattice, "_concurrent", lambda self: False)
+    assert big.boundary_depth() == (1 if concurrent else 2)     # one slice per side / a quarter of the narrowest slab
     for s in range(2):
         big.sweep(1)
         lat.sweep(1)
@@ -228,6 +232,8 @@ def test_biglattice_boundary_first_update_on_one_gpu():
         big.engines[0].ctx.update_range(0, 0, 8, 1)
     with pytest.raises(q.QcdError):
         big.engines[0].ctx.update_range(0, 0, 0, 9)
+    with pytest.raises(q.QcdError):
+        big.engines[0].ctx.update_split(0, 0, 0, 0)
     lat.close()
 
 
