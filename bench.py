@@ -220,6 +220,18 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     if world == 1 and not args.no_cpu:
+        # BASELINE configuration 5 beside the headline workload (not part of `value`): the O(N)
+        # scalar model, 64^4 in single precision, NHIT = 10, site updates per second from HIP events
+        try:
+            with q.OnContext((64, 64, 64, 64), precision=0, nhit=10, rand_series=7, device=local_rank) as oc:
+                oc.init_lattice()
+                oc.sweep(5)
+                on_ms = oc.timed_sweeps(20)
+                result["other_workloads"] = {"on_sigma_64x4_f32": {
+                    "site_updates_per_s": 64.0 ** 4 * 20 / (on_ms * 1e-3), "ms_per_sweep": on_ms / 20,
+                    "workload": "O(N) scalar model 64^4, single precision, NHIT=10, RANLUX3, cold start, 20 sweeps"}}
+        except q.QcdError as e:
+            log("O(N) leg skipped: %s" % e)
         log("CPU baseline leg (bounded sample, one core)")
         result["cpu_baseline"] = cpu_baseline(log)
     else:
