@@ -81,6 +81,10 @@ struct qcd_ctx {
     double2* partial;
     int npartial;
     long partial_len;         // double2 elements allocated for partial
+    double2* loops;           // Polyakov loop (Re, Im) of every owned space site, index y + Ny (z + Nz xs)
+    bool loops_fresh;         // loops belongs to the present links: the last call on the context wrote it
+    double2* site_vals;       // plaquette sums (space-like, time-like) of every owned site; allocated by the
+    bool sites_fresh;         // first plaquette profile, then kept up by every plaquette measurement
     int result_len;           // doubles in result_dev / result_host
     double* result_dev;
     double* result_host;  // pinned
@@ -365,9 +369,12 @@ int seed_streams(qcd_ctx* c)
 }
 
 // join = false: the call may run beside the side lane of qcd_update_split (halo messages only)
-int check_ctx(qcd_ctx* c, bool need_init, bool join = true)
+// reads_links: the call leaves the links as they are (measurements), so the per-site arrays of the
+// profile measurements stay valid; every other call invalidates them
+int check_ctx(qcd_ctx* c, bool need_init, bool join = true, bool reads_links = false)
 {
     if (!c) return fail(QCD_ERR_INVALID, "null context");
+    if (!reads_links) c->loops_fresh = c->sites_fresh = false;
     if (need_init && !c->initialized) return fail(QCD_ERR_STATE, "lattice not initialised: call qcd_init_lattice or qcd_upload first");
     int rc = set_device(c);
     if (rc) return rc;
@@ -514,6 +521,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     c->partial_len = 6L * c->npartial > 64L * max_ext ? 6L * c->npartial : 64L * max_ext;
     c->result_len = 2 * max_ext > 16 ? 2 * max_ext : 16;
     tryhip(hipMalloc(&c->partial, (size_t)c->partial_len * sizeof(double2)), "hipMalloc(partials)");
+    tryhip(hipMalloc(&c->loops, (size_t)g.nx * g.ny * g.nz * sizeof(double2)), "hipMalloc(polyakov loops)");
     tryhip(hipMalloc(&c->result_dev, c->result_len * sizeof(double)), "hipMalloc(result)");
     tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double)), "hipHostMalloc(result)");
     tryhip(hipMalloc(&c->draws_dev, sizeof(unsigned long long)), "hipMalloc(draws)");
@@ -547,6 +555,8 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipFree(c->edge_buf);
     if (c->edge_ev) (void)hipEventDestroy(c->edge_ev);
     (void)hipFree(c->partial);
+    (void)hipFree(c->loops);
+    (void)hipFree(c->site_vals);
     (void)hipFree(c->result_dev);
     (void)hipFree(c->draws_dev);
     (void)hipFree(c->redo_list);
@@ -731,17 +741,26 @@ int qcd_reunitarize(qcd_ctx* c)
     return tm.finish();
 }
 
+static int launch_plaquette(qcd_ctx* c)
+{
+    const dim3 grid(c->npartial), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, c->site_vals);
+    else hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, c->site_vals);
+    HIP_TRY(hipGetLastError());
+    return QCD_OK;
+}
+
 int qcd_measure_plaquette_sums(qcd_ctx* c, double sums[2])
 {
-    int rc = check_ctx(c, true);
+    int rc = check_ctx(c, true, true, true);
     if (rc) return rc;
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     Timed tm(c, 1);
-    const dim3 grid(c->npartial), block(MEAS_BLOCK);
-    if (c->p.group == 3) hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial);
-    else hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial);
+    if ((rc = launch_plaquette(c))) return rc;
     if ((rc = tm.finish())) return rc;
-    return reduce_partials(c, c->npartial, 1, sums);
+    if ((rc = reduce_partials(c, c->npartial, 1, sums))) return rc;
+    c->sites_fresh = c->site_vals != nullptr;
+    return QCD_OK;
 }
 
 int qcd_measure_plaquette(qcd_ctx* c, double out[3])
@@ -770,7 +789,7 @@ int qcd_measure_action(qcd_ctx* c, double out[3])
 
 int qcd_measure_wilson(qcd_ctx* c, int R, int T, double* out)
 {
-    int rc = check_ctx(c, true);
+    int rc = check_ctx(c, true, true, true);
     if (rc) return rc;
     if (!out) return fail(QCD_ERR_INVALID, "null output");
     if (R < 1 || T < 1) return fail(QCD_ERR_INVALID, "Wilson loop %d x %d", R, T);
@@ -791,7 +810,7 @@ int qcd_measure_wilson(qcd_ctx* c, int R, int T, double* out)
 
 int qcd_measure_fmunu_sums(qcd_ctx* c, int field, int index1, int index2, double sums[12])
 {
-    int rc = check_ctx(c, true);
+    int rc = check_ctx(c, true, true, true);
     if (rc) return rc;
     if (field != 0 && field != 1) return fail(QCD_ERR_INVALID, "field %d is not 0 (xy, xz, yz) or 1 (xt, yt, zt)", field);
     const int top = c->p.group == 3 ? 8 : 3;   // Gell-Mann or Pauli matrices
@@ -821,33 +840,62 @@ int qcd_measure_fmunu(qcd_ctx* c, int field, int index1, int index2, double out[
     return QCD_OK;
 }
 
-// shared driver of the two profile measurements
+// the loop of every owned space site into c->loops (and the four global sums into c->partial)
+static int launch_polyakov(qcd_ctx* c, int nb)
+{
+    const dim3 grid(nb), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_polyakov<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb, c->loops);
+    else hipLaunchKernelGGL((k_polyakov<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb, c->loops);
+    HIP_TRY(hipGetLastError());
+    return QCD_OK;
+}
+
+// shared driver of the two profile measurements.  A profile reads the per-site values that the
+// last Polyakov (plaquette) measurement left, when no other call came between: a sample's global
+// value and its three profiles then cost one pass over the links instead of four.
 static int measure_profile(qcd_ctx* c, int axis, double* sums, bool polyakov)
 {
-    int rc = check_ctx(c, true);
+    int rc = check_ctx(c, true, true, true);
     if (rc) return rc;
     if (axis < 0 || axis > 2) return fail(QCD_ERR_INVALID, "axis %d is not 0 (x), 1 (y) or 2 (z)", axis);
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     const Geom& g = c->g;
     const int ext = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
-    const long sites = polyakov ? (long)g.nx * g.ny * g.nz : (long)g.nx * g.gslice;
+    if (polyakov) {
+        const int n3 = g.nx * g.ny * g.nz;
+        const int nb = cdiv(n3, MEAS_BLOCK);
+        if (nb > c->npartial || ext > c->partial_len || 2 * ext > c->result_len)
+            return fail(QCD_ERR_UNSUPPORTED, "profile of %d planes does not fit the reduction buffers", ext);
+        Timed tm(c, 1);
+        if (!c->loops_fresh && (rc = launch_polyakov(c, nb))) return rc;
+        hipLaunchKernelGGL((k_loops_profile<MEAS_BLOCK>), dim3(ext), dim3(MEAS_BLOCK), 0, c->stream, c->loops, g, axis, c->partial);
+        HIP_TRY(hipGetLastError());
+        if ((rc = reduce_partials(c, 1, ext, sums))) return rc;
+        c->loops_fresh = true;
+        return tm.finish();
+    }
+    const long sites = (long)g.nx * g.gslice;
     const int plane = (int)(sites / ext);
     int chunks = cdiv(plane, MEAS_BLOCK);
     if (chunks > 64) chunks = 64;
     if ((long)ext * chunks > c->partial_len || 2 * ext > c->result_len)
         return fail(QCD_ERR_UNSUPPORTED, "profile of %d planes does not fit the reduction buffers", ext);
-    Timed tm(c, 1);
-    const dim3 grid(ext * chunks), block(MEAS_BLOCK);
-    if (c->p.group == 3) {
-        if (polyakov) hipLaunchKernelGGL((k_polyakov_profile<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
-        else hipLaunchKernelGGL((k_plaquette_profile<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
-    } else {
-        if (polyakov) hipLaunchKernelGGL((k_polyakov_profile<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
-        else hipLaunchKernelGGL((k_plaquette_profile<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, axis, chunks, plane, c->partial);
+    bool have = c->sites_fresh;
+    if (!c->site_vals) {   // first plaquette profile of this context
+        hipError_t e = hipMalloc(&c->site_vals, (size_t)2 * g.vh_int * sizeof(double2));
+        if (e != hipSuccess) {
+            c->site_vals = nullptr;
+            return fail(e == hipErrorOutOfMemory ? QCD_ERR_NOMEM : QCD_ERR_HIP, "hipMalloc(per-site plaquettes): %s", hipGetErrorString(e));
+        }
+        have = false;
     }
+    Timed tm(c, 1);
+    if (!have && (rc = launch_plaquette(c))) return rc;
+    hipLaunchKernelGGL((k_sites_profile<MEAS_BLOCK>), dim3(ext * chunks), dim3(MEAS_BLOCK), 0, c->stream, c->site_vals, g, axis, chunks,
+                       plane, c->partial);
     HIP_TRY(hipGetLastError());
-    rc = reduce_partials(c, chunks, ext, sums);
-    if (rc) return rc;
+    if ((rc = reduce_partials(c, chunks, ext, sums))) return rc;
+    c->sites_fresh = true;
     return tm.finish();
 }
 
@@ -856,18 +904,18 @@ int qcd_measure_polyakov_profile_sums(qcd_ctx* c, int axis, double* sums) { retu
 
 int qcd_measure_polyakov_sums(qcd_ctx* c, double sums[4])
 {
-    int rc = check_ctx(c, true);
+    int rc = check_ctx(c, true, true, true);
     if (rc) return rc;
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     const int n3 = c->g.nx * c->g.ny * c->g.nz;
     const int nb = cdiv(n3, MEAS_BLOCK);
     if (nb > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
     Timed tm(c, 1);
-    const dim3 grid(nb), block(MEAS_BLOCK);
-    if (c->p.group == 3) hipLaunchKernelGGL((k_polyakov<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb);
-    else hipLaunchKernelGGL((k_polyakov<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb);
+    if ((rc = launch_polyakov(c, nb))) return rc;
     if ((rc = tm.finish())) return rc;
-    return reduce_partials(c, nb, 2, sums);
+    if ((rc = reduce_partials(c, nb, 2, sums))) return rc;
+    c->loops_fresh = true;
+    return QCD_OK;
 }
 
 int qcd_measure_polyakov(qcd_ctx* c, double out[4])

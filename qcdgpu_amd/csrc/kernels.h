@@ -1017,9 +1017,11 @@ __device__ __forceinline__ void block_reduce_store(double a, double b, double2* 
     }
 }
 
+// site_vals (may be null): the (space-like, time-like) sums of every site, index par * vh_int + interior
+// half index, for the profiles below
 template <int GROUP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__ U, const Geom g,
-                                                     double2* __restrict__ partial)
+                                                     double2* __restrict__ partial, double2* __restrict__ site_vals)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     double spat = 0.0, temp = 0.0;
@@ -1046,6 +1048,7 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
             temp += retr_plaquette<GROUP>(U, g, x, 1, 3);
             temp += retr_plaquette<GROUP>(U, g, x, 2, 3);
         }
+        if (site_vals) site_vals[t] = make_double2(spat, temp);
     }
     block_reduce_store<BLOCK>(spat, temp, partial);
 }
@@ -1124,11 +1127,13 @@ __global__ __launch_bounds__(BLOCK) void k_wilson(const double2* __restrict__ U,
 // ---------------------------------------------------------------------------------------------
 // Polyakov loop (SU(N)/suncl/su3cpu.cpp:1383-1433; kernel lattice_polyakov,
 // SU(N)/suncl/polyakov.cl:53-141): P = Tr prod_{t=0}^{Nt-1} U_T(x,t), left to right from t = 0.
-// partial[0][block] = (sum Re P, sum Im P), partial[1][block] = (sum |P|^2, sum |P|^4)
+// partial[0][block] = (sum Re P, sum Im P), partial[1][block] = (sum |P|^2, sum |P|^4);
+// loops[y + Ny (z + Nz xs)] = P of that space site, for the profiles below.
 
 template <int GROUP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_polyakov(const double2* __restrict__ U, const Geom g,
-                                                    double2* __restrict__ partial, const int nblocks)
+                                                    double2* __restrict__ partial, const int nblocks,
+                                                    double2* __restrict__ loops)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     const int n3 = g.nx * g.ny * g.nz;
@@ -1151,6 +1156,7 @@ __global__ __launch_bounds__(BLOCK) void k_polyakov(const double2* __restrict__ 
         im = tr.im;
         p2 = re * re + im * im;
         p4 = p2 * p2;
+        loops[t] = make_double2(re, im);
     }
     // two independent reductions; the helper owns its LDS, so run it twice through a barrier
     block_reduce_store<BLOCK>(re, im, partial);
@@ -1235,14 +1241,15 @@ __global__ __launch_bounds__(BLOCK) void k_fmunu(const double2* __restrict__ U, 
 // and lattice_polyakov_diff_{x,y,z}, SU(N)/suncl/polyakov.cl:142-402): the plaquette sums and the
 // Polyakov loops of the sites with coordinate b along `axis` (0 = x, 1 = y, 2 = z).  Workgroup
 // (b, c) = blockIdx.x / chunks, blockIdx.x % chunks sums every chunks-th stretch of BLOCK sites of
-// plane b; k_reduce adds the chunks of a plane in index order.  Rarely run: written for
-// clarity, not for coalescing.
+// plane b; k_reduce adds the chunks of a plane in index order.  Both profiles read per-site values
+// that the global measurement's kernel leaves behind (k_plaquette's site_vals, k_polyakov's loops),
+// so a profile costs one pass over a small array, not another pass over the links.
 
-// site number j of the plane: the coordinates other than `axis` run y, z, (t,) x from fastest to slowest
-__device__ __forceinline__ Site plane_site(const Geom& g, int axis, int b, int j, bool with_t)
+// site number j of the plane: the coordinates other than `axis` run y, z, t, x from fastest to slowest
+__device__ __forceinline__ Site plane_site(const Geom& g, int axis, int b, int j)
 {
     int c[4];   // xs, y, z, t
-    const int ext[4] = {g.nx, g.ny, g.nz, with_t ? g.nt : 1};
+    const int ext[4] = {g.nx, g.ny, g.nz, g.nt};
     const int order[4] = {1, 2, 3, 0};
     c[3] = 0;
     for (int k = 0; k < 4; k++) {
@@ -1257,42 +1264,44 @@ __device__ __forceinline__ Site plane_site(const Geom& g, int axis, int b, int j
     return s;
 }
 
-template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_plaquette_profile(const double2* __restrict__ U, const Geom g, const int axis,
-                                                             const int chunks, const int plane_sites,
-                                                             double2* __restrict__ partial)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sites_profile(const double2* __restrict__ site_vals, const Geom g, const int axis,
+                                                         const int chunks, const int plane_sites,
+                                                         double2* __restrict__ partial)
 {
     const int b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
     double spat = 0.0, temp = 0.0;
     for (int j = c * BLOCK + threadIdx.x; j < plane_sites; j += chunks * BLOCK) {
-        const Site x = plane_site(g, axis, b, j, true);
-        spat += retr_plaquette<GROUP>(U, g, x, 0, 1);
-        spat += retr_plaquette<GROUP>(U, g, x, 0, 2);
-        spat += retr_plaquette<GROUP>(U, g, x, 1, 2);
-        temp += retr_plaquette<GROUP>(U, g, x, 0, 3);
-        temp += retr_plaquette<GROUP>(U, g, x, 1, 3);
-        temp += retr_plaquette<GROUP>(U, g, x, 2, 3);
+        const Site x = plane_site(g, axis, b, j);
+        const int h = ((x.xs * g.nt + x.t) * g.nz + x.z) * g.nyh + (x.y >> 1);
+        const double2 v = site_vals[(size_t)site_parity(g, x) * g.vh_int + h];
+        spat += v.x;
+        temp += v.y;
     }
     block_reduce_store<BLOCK>(spat, temp, partial);
 }
 
-template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_polyakov_profile(const double2* __restrict__ U, const Geom g, const int axis,
-                                                            const int chunks, const int plane_sites,
-                                                            double2* __restrict__ partial)
+// Polyakov profile from the per-site loops k_polyakov wrote: workgroup b adds the loops of the
+// space sites with coordinate b along `axis`; partial[b] = (sum Re P, sum Im P).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_loops_profile(const double2* __restrict__ loops, const Geom g, const int axis,
+                                                         double2* __restrict__ partial)
 {
-    const int b = blockIdx.x / chunks, c = blockIdx.x - b * chunks;
+    const int b = blockIdx.x;
+    const int n3 = g.nx * g.ny * g.nz;
+    const int plane_sites = n3 / (axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz));
     double re = 0.0, im = 0.0;
-    for (int j = c * BLOCK + threadIdx.x; j < plane_sites; j += chunks * BLOCK) {
-        Site x = plane_site(g, axis, b, j, false);
-        mat<GROUP> m = load_site_link<GROUP>(U, g, 3, x);
-        for (int tt = 1; tt < g.nt; tt++) {
-            x.t = tt;
-            m = mul(m, load_site_link<GROUP>(U, g, 3, x));
+    for (int j = threadIdx.x; j < plane_sites; j += BLOCK) {
+        int s;
+        if (axis == 0) s = b * g.ny * g.nz + j;
+        else if (axis == 1) s = b + g.ny * j;
+        else {
+            const int xs = j / g.ny;
+            s = (j - xs * g.ny) + g.ny * (b + g.nz * xs);
         }
-        const cplx tr = trace(m);
-        re += tr.re;
-        im += tr.im;
+        const double2 p = loops[s];
+        re += p.x;
+        im += p.y;
     }
     block_reduce_store<BLOCK>(re, im, partial);
 }

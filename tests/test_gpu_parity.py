@@ -310,6 +310,18 @@ def test_plane_profiles_match_checker(group, L):
             assert np.allclose(gp.sum(axis=0), psums[:2], rtol=1e-11, atol=1e-12)
         with pytest.raises(q.QcdError):
             c.plaquette_profile_sums(3)
+        # the profiles reuse per-site values of the last global measurement: a sweep in between
+        # must make them stale (profiles first, then once more after the global measurements)
+        c.sweep(1)
+        lat.sweep(1)
+        for again in range(2):
+            for axis in (1, 0, 2):
+                got, want = c.plaquette_profile_sums(axis), lat.plaquette_profile_sums(axis)
+                assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12
+                gp, wp = c.polyakov_profile_sums(axis), lat.polyakov_profile_sums(axis)
+                assert np.allclose(gp, wp, rtol=1e-10, atol=1e-12)
+            c.plaquette_sums()
+            c.polyakov_sums()
     lat.close()
 
 
