@@ -423,6 +423,13 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
         return fail(QCD_ERR_INVALID, "halo = 0 requires the context to own the whole lattice in x");
     const long sites = (long)p->L[0] * p->L[1] * p->L[2] * p->L[3];
     if (sites > (1L << 30)) return fail(QCD_ERR_UNSUPPORTED, "lattice of %ld sites exceeds 2^30", sites);
+    {
+        // the kernels address a direction's links through 32-bit byte offsets (buffer descriptors)
+        const long vh = (long)(p->nx_local + 2 * p->halo) * (p->L[1] / 2) * p->L[2] * p->L[3];
+        const long bytes = 2L * (p->group == 3 ? 6 : 2) * vh * 16;
+        if (bytes >= (1L << 31))
+            return fail(QCD_ERR_UNSUPPORTED, "%ld bytes of links per direction on one device exceed 2^31: cut the lattice into more parts", bytes);
+    }
 
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));

@@ -1005,13 +1005,14 @@ __device__ __forceinline__ cplx cross_c(cplx a1, cplx a2, cplx b1, cplx b2)   //
     return csub(cmul(a1, b2), cmul(a2, b1));
 }
 // a = two rows of U_mu(x), d = two rows of U_nu(x) (kept by the caller: a site's four own links
-// serve three planes each), b = U_nu(x+mu), c = U_mu(x+nu) loaded here
-__device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__ U, const Geom& g, const int hb,
-                                                     const NbrOff& n, const int par, const int mu, const int nu,
+// serve three planes each), b = U_nu(x+mu), c = U_mu(x+nu) loaded here.  ob = byte offset of the
+// other parity's half of a direction's array plus the site's own offset (link_rsrc_both).
+__device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__ U, const Geom& g, const unsigned ob,
+                                                     const NbrOff& n, const int mu, const int nu,
                                                      const rows2& a, const rows2& d)
 {
-    const raw_link rb = issue_link(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_fwd(n, mu));
-    const raw_link rc = issue_link(link_rsrc<3>(U, g, mu, par ^ 1), g, hb + off_fwd(n, nu));
+    const raw_link rb = issue_link(link_rsrc_both<3>(U, g, nu), g, (int)(ob + (unsigned)off_fwd(n, mu)));
+    const raw_link rc = issue_link(link_rsrc_both<3>(U, g, mu), g, (int)(ob + (unsigned)off_fwd(n, nu)));
     const su3 b = as_su3(rb);
     const su3 c = as_su3(rc);
     cplx p[2][3], q[2][3];
@@ -1035,6 +1036,31 @@ __device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__
         re += cp.re * cq.re + cp.im * cq.im;
     }
     return re;
+}
+
+// Thread -> site for the measurement kernels: storage order with BOTH parities side by side
+// (y fastest, then z, t, x), and the workgroups dealt to the XCDs in eight contiguous runs.  A
+// link is asked for several times -- as a site's own link and as the neighbour of others -- and
+// this way the requests come from the same wave or from workgroups that run on the same XCD at
+// about the same time, so most of them find the line in that XCD's L2.  (One parity after the
+// other, as the update pass has it, puts them 100 us apart: the plaquette kernel then fetched
+// 3.4 times the lattice per call; plaquette 205 -> 158 us at 32^4.)  False: no site for this thread.
+template <int BLOCK>
+__device__ __forceinline__ bool measurement_site(const Geom& g, Site& x)
+{
+    const int nb = gridDim.x;
+#ifdef QCD_PLAQ_NO_XCD
+    const int lb = blockIdx.x;
+#else
+    const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+#endif
+    int r = lb * BLOCK + threadIdx.x;
+    if (r >= 2 * g.vh_int) return false;
+    x.y = r % g.ny; r /= g.ny;
+    x.z = r % g.nz; r /= g.nz;
+    x.t = r % g.nt;
+    x.xs = r / g.nt;
+    return true;
 }
 
 template <int BLOCK>
@@ -1064,28 +1090,29 @@ __device__ __forceinline__ void block_reduce_store(double a, double b, double2* 
 }
 
 // site_vals (may be null): the (space-like, time-like) sums of every site, index par * vh_int + interior
-// half index, for the profiles below
+// half index, for the profiles below.
 template <int GROUP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__ U, const Geom g,
                                                      double2* __restrict__ partial, double2* __restrict__ site_vals)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
     double spat = 0.0, temp = 0.0;
-    if (t < 2 * g.vh_int) {
-        const int par = t / g.vh_int;
-        const Site x = site_of(g, t - par * g.vh_int, par);
+    Site x;
+    if (measurement_site<BLOCK>(g, x)) {
+        const int par = site_parity(g, x);
         if constexpr (GROUP == 3) {
-            const int hb = half_index(g, x) * 16;
+            const unsigned hb = (unsigned)half_index(g, x) * 16u;
+            const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * 16u;
+            const unsigned own_off = (par ? pbytes : 0u) + hb, other_off = (par ? 0u : pbytes) + hb;
             const NbrOff n = neighbour_offsets(g, x);
             rows2 own[4];
 #pragma unroll
-            for (int d = 0; d < 4; d++) own[d] = as_rows2(issue_link(link_rsrc<3>(U, g, d, par), g, hb));
-            spat += retr_plaquette_su3(U, g, hb, n, par, 0, 1, own[0], own[1]);
-            spat += retr_plaquette_su3(U, g, hb, n, par, 0, 2, own[0], own[2]);
-            spat += retr_plaquette_su3(U, g, hb, n, par, 1, 2, own[1], own[2]);
-            temp += retr_plaquette_su3(U, g, hb, n, par, 0, 3, own[0], own[3]);
-            temp += retr_plaquette_su3(U, g, hb, n, par, 1, 3, own[1], own[3]);
-            temp += retr_plaquette_su3(U, g, hb, n, par, 2, 3, own[2], own[3]);
+            for (int d = 0; d < 4; d++) own[d] = as_rows2(issue_link(link_rsrc_both<3>(U, g, d), g, (int)own_off));
+            spat += retr_plaquette_su3(U, g, other_off, n, 0, 1, own[0], own[1]);
+            spat += retr_plaquette_su3(U, g, other_off, n, 0, 2, own[0], own[2]);
+            spat += retr_plaquette_su3(U, g, other_off, n, 1, 2, own[1], own[2]);
+            temp += retr_plaquette_su3(U, g, other_off, n, 0, 3, own[0], own[3]);
+            temp += retr_plaquette_su3(U, g, other_off, n, 1, 3, own[1], own[3]);
+            temp += retr_plaquette_su3(U, g, other_off, n, 2, 3, own[2], own[3]);
         } else {
             spat += retr_plaquette<GROUP>(U, g, x, 0, 1);
             spat += retr_plaquette<GROUP>(U, g, x, 0, 2);
@@ -1094,7 +1121,10 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
             temp += retr_plaquette<GROUP>(U, g, x, 1, 3);
             temp += retr_plaquette<GROUP>(U, g, x, 2, 3);
         }
-        if (site_vals) site_vals[t] = make_double2(spat, temp);
+        if (site_vals) {
+            const int h = ((x.xs * g.nt + x.t) * g.nz + x.z) * g.nyh + (x.y >> 1);
+            site_vals[(size_t)par * g.vh_int + h] = make_double2(spat, temp);
+        }
     }
     block_reduce_store<BLOCK>(spat, temp, partial);
 }
@@ -1151,11 +1181,9 @@ template <int GROUP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_wilson(const double2* __restrict__ U, const Geom g, const int R, const int T,
                                                   double2* __restrict__ partial)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
     double sum = 0.0;
-    if (t < 2 * g.vh_int) {
-        const int par = t / g.vh_int;
-        const Site p = site_of(g, t - par * g.vh_int, par);
+    Site p;
+    if (measurement_site<BLOCK>(g, p)) {
         Site pT = p;
         const mat<GROUP> m1 = link_line<GROUP>(U, g, pT, 3, T);
 #pragma unroll 1
@@ -1252,13 +1280,11 @@ template <int GROUP, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_fmunu(const double2* __restrict__ U, const Geom g, const int field, const int index1,
                                                  const int index2, double2* __restrict__ partial, const int nblocks)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
     double f[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) f[k] = 0.0;
-    if (t < 2 * g.vh_int) {
-        const int par = t / g.vh_int;
-        const Site x = site_of(g, t - par * g.vh_int, par);
+    Site x;
+    if (measurement_site<BLOCK>(g, x)) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int mu = field ? k : (k == 2 ? 1 : 0);

@@ -219,6 +219,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc(const double2* U, co
                                              ncomp<GROUP>::value * g.vh_alloc * 16, 0x00020000);
 }
 
+// both parities of one direction behind one descriptor: the second parity's links start
+// ncomp * vh_alloc * 16 bytes behind the first's (for kernels whose waves hold sites of both)
+template <int GROUP>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc_both(const double2* U, const Geom& g, int dir)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(U + comp_base<GROUP>(g, dir, 0)), 0,
+                                             2 * ncomp<GROUP>::value * g.vh_alloc * 16, 0x00020000);
+}
+
 // byte_off = 16 * half index
 __device__ __forceinline__ su3 load_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, su3*)
 {
