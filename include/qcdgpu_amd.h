@@ -42,7 +42,7 @@ enum { QCD_START_HOT = 0, QCD_START_COLD = 1, QCD_START_GID = 2 };
 typedef struct {
     int      group;        /* lattice_group: 2 or 3 */
     int      nd;           /* lattice_nd: 4 */
-    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (Ny even) */
+    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (all even: QCD_ERR_UNSUPPORTED otherwise) */
     int      precision;    /* 2 = double (model_precision_double); others unsupported */
     double   beta;         /* BETA */
     int      nhit;         /* NHIT: max heat-bath trials per SU(2) subgroup */
@@ -225,7 +225,7 @@ typedef struct qcd_on_ctx qcd_on_ctx;
 /* run_parameters of the O(N) model (O(N)/suncl/suncl.h:74-102; init keys SKGROUP, ON_Z, ON_LAMBDA,
  * ON_ZETA, ON_ETA, ON_B, O(N)/suncl/suncl.cpp:273-286) */
 typedef struct {
-    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (Ny even) */
+    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (all even: QCD_ERR_UNSUPPORTED otherwise) */
     int      precision;    /* 0 = single, 1 = double (model_precision_single / _double) */
     int      nhit;         /* NHIT: proposals per site and pass */
     int      sk_group;     /* ON_SK_group: N of the O(N) group in the action */

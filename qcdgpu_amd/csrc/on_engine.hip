@@ -211,6 +211,11 @@ int qcd_on_create(qcd_on_ctx** out, const qcd_on_params* p)
     for (int i = 0; i < 4; i++)
         if (p->L[i] < 2) return fail(QCD_ERR_INVALID, "lattice extent L[%d] = %d < 2", i, p->L[i]);
     if (p->L[1] & 1) return fail(QCD_ERR_INVALID, "Ny = %d must be even (checkerboard pairs sites 2h, 2h+1)", p->L[1]);
+    // the field is stored by parity and a neighbour is looked up in the other parity's array: across
+    // the periodic wrap of an odd extent the neighbour has the SAME parity
+    if ((p->L[0] | p->L[2] | p->L[3]) & 1)
+        return fail(QCD_ERR_UNSUPPORTED, "odd lattice extents are not supported (%d x %d x %d x %d): the checkerboard does not close", p->L[0],
+                    p->L[1], p->L[2], p->L[3]);
     if (p->precision != 0 && p->precision != 1) return fail(QCD_ERR_UNSUPPORTED, "precision must be 0 (single) or 1 (double), got %d", p->precision);
     if (p->nhit < 1) return fail(QCD_ERR_INVALID, "NHIT = %d < 1", p->nhit);
     if (p->sk_group < 1) return fail(QCD_ERR_INVALID, "SKGROUP = %d < 1", p->sk_group);

@@ -106,6 +106,17 @@ def test_no_device_is_an_error_code_not_a_crash():
         q.Context(group=3, L=(4, 4, 4, 4), beta=6.0)
 
 
+def test_odd_extents_are_refused_before_any_device_work():
+    """Links and scalar field are stored by parity; an odd extent would make a site and its neighbour
+    across the periodic wrap the same parity.  Both engines say so instead of computing nonsense."""
+    import qcdgpu_amd as q
+    for L in ((5, 4, 4, 4), (4, 4, 3, 4), (4, 4, 4, 7), (4, 5, 4, 4)):
+        with pytest.raises(q.QcdError, match="odd|even"):
+            q.Context(group=3, L=L, beta=6.0)
+        with pytest.raises(q.QcdError, match="odd|even"):
+            q.OnContext(L=L)
+
+
 def test_ranlux_batch_formulation_equals_reference_generator():
     import qcdgpu_amd as q
     for lux, nskip in enumerate((24, 48, 97, 223, 389)):
