@@ -361,3 +361,30 @@ def test_cli_fmunu_columns(tmp_path):
         assert rows[i, 25] == pytest.approx(math.sqrt(f[7] ** 2 + f[9] ** 2 + f[11] ** 2), rel=1e-10)
     lat.close()
     assert np.allclose(rows2, rows, rtol=1e-10, atol=1e-14)
+
+
+def test_64x4_lattice_one_context_equals_two_slabs():
+    """Size-independent property at a large size (1.6 GB of links per direction: exercises the 32-bit
+    buffer offsets): the random streams are keyed by the global site, so a 64^4 SU(3) lattice in one
+    context and the same lattice cut into two slabs give the same plaquette sums digit for digit;
+    the y-profile adds up to the lattice sum; cold start gives exactly N."""
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    L = (64, 64, 64, 64)
+    with q.Context(group=3, L=L, beta=6.0, nhit=10, rand_series=54) as c:
+        c.init_lattice()
+        assert c.plaquette()[2] == 3.0
+        c.sweep(1)
+        one_p, one_l = c.plaquette_sums(), c.polyakov_sums()
+        assert np.allclose(c.plaquette_profile_sums(1).sum(axis=0), one_p, rtol=1e-12)
+        assert 2.0 < one_p.sum() / (6 * 64 ** 4) < 2.2   # first sweep from cold at beta = 6
+    big = bl.make_gpu_slabs(3, L, 6.0, [32, 32], nhit=10, rand_series=54)
+    try:
+        big.sweep(1)
+        two_p = np.sum([e.plaquette_sums() for e in big.engines], axis=0)
+        two_l = np.sum([e.polyakov_sums() for e in big.engines], axis=0)
+    finally:
+        for e in big.engines:
+            e.ctx.close()
+    assert np.allclose(one_p, two_p, rtol=1e-13)
+    assert np.allclose(one_l, two_l, rtol=1e-10, atol=1e-8)
