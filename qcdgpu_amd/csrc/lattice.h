@@ -269,7 +269,7 @@ __device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const G
 #pragma unroll
     for (int c = 0; c < 2; c++)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(m.e[0][c].re, m.e[0][c].im)), r, byte_off,
-                                               c * g.vh_alloc * 16, 0);
+                                               c * g.vh_alloc * 16, QCD_STORE_AUX);
 }
 
 // byte offsets from a site's half index to its eight nearest neighbours (periodic wrap
