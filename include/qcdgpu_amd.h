@@ -145,7 +145,11 @@ int qcd_measure_fmunu_sums(qcd_ctx *ctx, int field, int index1, int index2, doub
  * lattice_polyakov_diff_*, polyakov.cl:142-402): profiles along a space axis (0 x, 1 y, 2 z).
  * sums[2*i], sums[2*i+1] = raw (spat, temp) ReTr plaquette sums resp. (Re P, Im P) sums over the
  * owned sites with coordinate i along the axis; i runs over nx_local (axis 0), Ny or Nz values.
- * The host turns them into S_s/S_t resp. PL/PL_im per plane (suncl.cpp:1116-1260). */
+ * The host turns them into S_s/S_t resp. PL/PL_im per plane (suncl.cpp:1116-1260).
+ * Cost: a profile is summed from per-site values that qcd_measure_plaquette(_sums) resp.
+ * qcd_measure_polyakov(_sums) leave on the device; they stay valid while only measurement calls are
+ * made on the context, otherwise the profile call recomputes them.  The first plaquette profile of a
+ * context allocates the per-site array (16 bytes per owned site). */
 int qcd_measure_plaquette_profile_sums(qcd_ctx *ctx, int axis, double *sums);
 int qcd_measure_polyakov_profile_sums(qcd_ctx *ctx, int axis, double *sums);
 
