@@ -34,8 +34,8 @@ constexpr int RLX_WINDOW = 2;
 // generator state in front of its next batch.
 
 struct RlxView {
-    unsigned* slot0;    // [w * ns + stream], w in [0, 25): generator state in front of a batch
-    unsigned* slot1;    // second copy = slot0 + 25*ns (one allocation); ctl says which of the two is current
+    unsigned* slot0;    // [k * ns + stream], k in [0, 19): packed generator state in front of a batch
+    unsigned* slot1;    // second copy = slot0 + 19*ns (one allocation); ctl says which of the two is current
     unsigned* ctl;      // bit 0: slot that holds the state in front of the stream's next batch
     int ns;             // streams
     int q, rem;         // nskip = 24*q + rem
@@ -43,7 +43,7 @@ struct RlxView {
 
 // Where a stream's persistent state lives, and the moves both stream types share.
 struct RlxHome {
-    unsigned* __restrict__ s0;   // this stream's column in slot 0; slot 1 lies 25*ns words behind it
+    unsigned* __restrict__ s0;   // this stream's column in slot 0; slot 1 lies 19*ns words behind it
     unsigned* __restrict__ ctl;
     int ns, q, rem;
 
@@ -55,31 +55,31 @@ struct RlxHome {
         q = view.q;
         rem = view.rem;
     }
+    // Packed form in memory (rlx_pack4): [k * ns + stream], k in [0, 19).
+    // Non-temporal: a stream's state is read once and written once per pass, it should not take
+    // L2 room from the links (-1.5 % on the 32^4 update pass).
     __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
     {
-        const unsigned* __restrict__ p = s0 + (size_t)slot * RLX_STATE_WORDS * ns;
+        const unsigned* __restrict__ p = s0 + (size_t)slot * RLX_PACKED_WORDS * ns;
+        unsigned d[RLX_PACKED_WORDS];
 #pragma unroll
-        // non-temporal: a stream's state is read once and written once per pass, it should not
-        // take L2 room from the links (-1.5 % on the 32^4 update pass together with store_state)
-#ifdef QCD_RNG_TEMPORAL
-        for (int w = 0; w < 24; w++) r.s[w] = p[(size_t)w * ns];
-        r.c = p[(size_t)24 * ns];
-#else
-        for (int w = 0; w < 24; w++) r.s[w] = __builtin_nontemporal_load(p + (size_t)w * ns);
-        r.c = __builtin_nontemporal_load(p + (size_t)24 * ns);
-#endif
+        for (int k = 0; k < RLX_PACKED_WORDS; k++) d[k] = __builtin_nontemporal_load(p + (size_t)k * ns);
+#pragma unroll
+        for (int j = 0; j < 6; j++) rlx_unpack4(d[3 * j], d[3 * j + 1], d[3 * j + 2], r.s + 4 * j);
+        r.c = d[18];
     }
     __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
     {
-        unsigned* __restrict__ p = s0 + (size_t)slot * RLX_STATE_WORDS * ns;
+        unsigned* __restrict__ p = s0 + (size_t)slot * RLX_PACKED_WORDS * ns;
 #pragma unroll
-#ifdef QCD_RNG_TEMPORAL
-        for (int w = 0; w < 24; w++) p[(size_t)w * ns] = r.s[w];
-        p[(size_t)24 * ns] = r.c;
-#else
-        for (int w = 0; w < 24; w++) __builtin_nontemporal_store(r.s[w], p + (size_t)w * ns);
-        __builtin_nontemporal_store(r.c, p + (size_t)24 * ns);
-#endif
+        for (int j = 0; j < 6; j++) {
+            unsigned d0, d1, d2;
+            rlx_pack4(r.s + 4 * j, d0, d1, d2);
+            __builtin_nontemporal_store(d0, p + (size_t)(3 * j) * ns);
+            __builtin_nontemporal_store(d1, p + (size_t)(3 * j + 1) * ns);
+            __builtin_nontemporal_store(d2, p + (size_t)(3 * j + 2) * ns);
+        }
+        __builtin_nontemporal_store(r.c, p + (size_t)18 * ns);
     }
 };
 

@@ -28,6 +28,26 @@ struct RlxRegs {
     unsigned c;
 };
 
+// Device-memory form of a stream's state: the 24 words are 24-bit integers, so four of them fit
+// three 32-bit words (the fourth one's bytes ride in the top bytes of the other three); 18 words
+// + the carry = 19 instead of 25 per state.  The state is read and written once per link update
+// (an eighth of the update pass's memory traffic in unpacked form), the handful of byte moves is
+// cheap beside that.
+constexpr int RLX_PACKED_WORDS = 19;
+__host__ __device__ inline void rlx_pack4(const unsigned* s, unsigned& d0, unsigned& d1, unsigned& d2)
+{
+    d0 = s[0] | (s[3] << 24);
+    d1 = s[1] | ((s[3] >> 8) << 24);
+    d2 = s[2] | ((s[3] >> 16) << 24);
+}
+__host__ __device__ inline void rlx_unpack4(unsigned d0, unsigned d1, unsigned d2, unsigned* s)
+{
+    s[0] = d0 & 0xffffffu;
+    s[1] = d1 & 0xffffffu;
+    s[2] = d2 & 0xffffffu;
+    s[3] = (d0 >> 24) | ((d1 >> 24) << 8) | ((d2 >> 24) << 16);
+}
+
 // SU(N)/random/random.cpp:192-196
 __host__ __device__ inline int rlx_nskip_for_level(int level)
 {
