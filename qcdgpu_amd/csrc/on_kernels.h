@@ -146,25 +146,36 @@ struct RlxTileHome {
     __device__ __forceinline__ void bind(const RlxView& view, int stream)
     {
         const int tile = stream / ON_RLX_TILE;
-        s0 = view.slot0 + (size_t)tile * ON_RLX_TILE * RLX_STATE_WORDS + (stream - tile * ON_RLX_TILE);
+        s0 = view.slot0 + (size_t)tile * ON_RLX_TILE * RLX_PACKED_WORDS + (stream - tile * ON_RLX_TILE);
         ctl = view.ctl + stream;
         slot_stride = (size_t)(view.slot1 - view.slot0);
         q = view.q;
         rem = view.rem;
     }
+    // packed form in memory (rlx_pack4, 19 words per state): the generator state is most of what a
+    // pass of this model moves (one 4-byte field value per site against 2 x 76 bytes of state)
     __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
     {
         const unsigned* __restrict__ p = s0 + (size_t)slot * slot_stride;
+        unsigned d[RLX_PACKED_WORDS];
 #pragma unroll
-        for (int w = 0; w < 24; w++) r.s[w] = p[w * ON_RLX_TILE];
-        r.c = p[24 * ON_RLX_TILE];
+        for (int k = 0; k < RLX_PACKED_WORDS; k++) d[k] = __builtin_nontemporal_load(p + k * ON_RLX_TILE);
+#pragma unroll
+        for (int j = 0; j < 6; j++) rlx_unpack4(d[3 * j], d[3 * j + 1], d[3 * j + 2], r.s + 4 * j);
+        r.c = d[18];
     }
     __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
     {
         unsigned* __restrict__ p = s0 + (size_t)slot * slot_stride;
 #pragma unroll
-        for (int w = 0; w < 24; w++) p[w * ON_RLX_TILE] = r.s[w];
-        p[24 * ON_RLX_TILE] = r.c;
+        for (int j = 0; j < 6; j++) {
+            unsigned d0, d1, d2;
+            rlx_pack4(r.s + 4 * j, d0, d1, d2);
+            __builtin_nontemporal_store(d0, p + (3 * j) * ON_RLX_TILE);
+            __builtin_nontemporal_store(d1, p + (3 * j + 1) * ON_RLX_TILE);
+            __builtin_nontemporal_store(d2, p + (3 * j + 2) * ON_RLX_TILE);
+        }
+        __builtin_nontemporal_store(r.c, p + 18 * ON_RLX_TILE);
     }
 };
 
