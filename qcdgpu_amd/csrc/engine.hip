@@ -351,13 +351,13 @@ int seed_streams(qcd_ctx* c)
     // the lattice is cut into slabs
     const long first = (long)c->p.x0 * g.slice_h;
     std::vector<int> seeds = stream_seeds(c->p.rand_series, first, ns);
-    std::vector<unsigned> st((size_t)RLX_PACKED_WORDS * ns);
+    std::vector<unsigned> st((size_t)RLX_SLOT_WORDS * ns);
     for (int i = 0; i < ns; i++) {
         RlxRegs r;
+        unsigned d[RLX_SLOT_WORDS];
         rlx_seed_state(seeds[(size_t)i], nskip, r);
-        for (int j = 0; j < 6; j++)
-            rlx_pack4(r.s + 4 * j, st[(size_t)(3 * j) * ns + i], st[(size_t)(3 * j + 1) * ns + i], st[(size_t)(3 * j + 2) * ns + i]);
-        st[(size_t)18 * ns + i] = r.c;
+        rlx_pack(r, d);
+        for (int k = 0; k < RLX_SLOT_WORDS; k++) st[rlx_slot_index(k, (size_t)ns, (size_t)i)] = d[k];
     }
     HIP_TRY(hipMemcpyAsync(c->rv.slot0, st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->rv.slot1, 0, st.size() * sizeof(unsigned), c->stream));
@@ -523,9 +523,9 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipEventCreate(&c->ev0), "hipEventCreate");
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
     tryhip(hipMalloc(&c->U, c->U_elems * sizeof(double2)), "hipMalloc(links)");
-    const size_t stw = (size_t)RLX_PACKED_WORDS * g.vh_int * sizeof(unsigned);
+    const size_t stw = (size_t)RLX_SLOT_WORDS * g.vh_int * sizeof(unsigned);
     tryhip(hipMalloc(&c->rv.slot0, 2 * stw), "hipMalloc(ranlux)");   // both slots, back to back
-    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_PACKED_WORDS * g.vh_int : nullptr;
+    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_SLOT_WORDS * g.vh_int : nullptr;
     tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh_int * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
     c->rv.ns = g.vh_int;
     if (p->start_mode == QCD_START_GID)
@@ -1022,25 +1022,26 @@ static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
     h += sizeof(unsigned long long);
     HIP_TRY(cp(c->rv.ctl, h, ns * sizeof(unsigned)));
     h += ns * sizeof(unsigned);
-    std::vector<unsigned> packed((size_t)2 * RLX_PACKED_WORDS * ns);   // both slots, as on the device
-    unsigned* wide = (unsigned*)h;                                     // [slot][w][stream], w in [0, 25)
+    std::vector<unsigned> packed((size_t)2 * RLX_SLOT_WORDS * ns);   // both slots, as on the device
+    unsigned* wide = (unsigned*)h;                                   // [slot][w][stream], w in [0, 25)
     auto convert = [&](bool pack) {
         for (int slot = 0; slot < 2; slot++) {
-            unsigned* pk = packed.data() + (size_t)slot * RLX_PACKED_WORDS * ns;
+            unsigned* pk = packed.data() + (size_t)slot * RLX_SLOT_WORDS * ns;
             unsigned* wd = wide + (size_t)slot * RLX_STATE_WORDS * ns;
             for (size_t i = 0; i < ns; i++) {
-                unsigned s4[4];
-                for (int j = 0; j < 6; j++) {
-                    if (pack) {
-                        for (int k = 0; k < 4; k++) s4[k] = wd[(size_t)(4 * j + k) * ns + i] & 0xffffffu;
-                        rlx_pack4(s4, pk[(size_t)(3 * j) * ns + i], pk[(size_t)(3 * j + 1) * ns + i], pk[(size_t)(3 * j + 2) * ns + i]);
-                    } else {
-                        rlx_unpack4(pk[(size_t)(3 * j) * ns + i], pk[(size_t)(3 * j + 1) * ns + i], pk[(size_t)(3 * j + 2) * ns + i], s4);
-                        for (int k = 0; k < 4; k++) wd[(size_t)(4 * j + k) * ns + i] = s4[k];
-                    }
+                RlxRegs r;
+                unsigned d[RLX_SLOT_WORDS];
+                if (pack) {
+                    for (int w = 0; w < 24; w++) r.s[w] = wd[(size_t)w * ns + i] & 0xffffffu;
+                    r.c = wd[(size_t)24 * ns + i];
+                    rlx_pack(r, d);
+                    for (int k = 0; k < RLX_SLOT_WORDS; k++) pk[rlx_slot_index(k, ns, i)] = d[k];
+                } else {
+                    for (int k = 0; k < RLX_SLOT_WORDS; k++) d[k] = pk[rlx_slot_index(k, ns, i)];
+                    rlx_unpack(d, r);
+                    for (int w = 0; w < 24; w++) wd[(size_t)w * ns + i] = r.s[w];
+                    wd[(size_t)24 * ns + i] = r.c;
                 }
-                if (pack) pk[(size_t)18 * ns + i] = wd[(size_t)24 * ns + i];
-                else wd[(size_t)24 * ns + i] = pk[(size_t)18 * ns + i];
             }
         }
     };

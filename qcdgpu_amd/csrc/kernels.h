@@ -34,8 +34,8 @@ constexpr int RLX_WINDOW = 2;
 // generator state in front of its next batch.
 
 struct RlxView {
-    unsigned* slot0;    // [k * ns + stream], k in [0, 19): packed generator state in front of a batch
-    unsigned* slot1;    // second copy = slot0 + 19*ns (one allocation); ctl says which of the two is current
+    unsigned* slot0;    // packed generator state in front of a batch: quad q of a stream at word (q * ns + stream) * 4
+    unsigned* slot1;    // second copy = slot0 + 20*ns (one allocation); ctl says which of the two is current
     unsigned* ctl;      // bit 0: slot that holds the state in front of the stream's next batch
     int ns;             // streams
     int q, rem;         // nskip = 24*q + rem
@@ -43,43 +43,44 @@ struct RlxView {
 
 // Where a stream's persistent state lives, and the moves both stream types share.
 struct RlxHome {
-    unsigned* __restrict__ s0;   // this stream's column in slot 0; slot 1 lies 19*ns words behind it
+    unsigned* __restrict__ s0;   // this stream's first quad in slot 0; slot 1 lies 20*ns words behind it
     unsigned* __restrict__ ctl;
     int ns, q, rem;
 
     __device__ __forceinline__ void bind(const RlxView& view, int stream)
     {
-        s0 = view.slot0 + stream;
+        s0 = view.slot0 + (size_t)4 * stream;
         ctl = view.ctl + stream;
         ns = view.ns;
         q = view.q;
         rem = view.rem;
     }
-    // Packed form in memory (rlx_pack4): [k * ns + stream], k in [0, 19).
+    // Packed form in memory (rlx_pack): five 16-byte quads per state, quad q at word (q * ns + stream) * 4.
     // Non-temporal: a stream's state is read once and written once per pass, it should not take
-    // L2 room from the links (-1.5 % on the 32^4 update pass).
+    // L2 room from the links.
+    typedef unsigned quad_t __attribute__((ext_vector_type(4)));
     __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
     {
-        const unsigned* __restrict__ p = s0 + (size_t)slot * RLX_PACKED_WORDS * ns;
-        unsigned d[RLX_PACKED_WORDS];
+        const quad_t* __restrict__ p = (const quad_t*)(s0 + (size_t)slot * RLX_SLOT_WORDS * ns);
+        unsigned d[RLX_SLOT_WORDS];
 #pragma unroll
-        for (int k = 0; k < RLX_PACKED_WORDS; k++) d[k] = __builtin_nontemporal_load(p + (size_t)k * ns);
-#pragma unroll
-        for (int j = 0; j < 6; j++) rlx_unpack4(d[3 * j], d[3 * j + 1], d[3 * j + 2], r.s + 4 * j);
-        r.c = d[18];
+        for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
+            const quad_t v = __builtin_nontemporal_load(p + (size_t)q4 * ns);
+            d[4 * q4] = v.x; d[4 * q4 + 1] = v.y; d[4 * q4 + 2] = v.z; d[4 * q4 + 3] = v.w;
+        }
+        rlx_unpack(d, r);
     }
     __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
     {
-        unsigned* __restrict__ p = s0 + (size_t)slot * RLX_PACKED_WORDS * ns;
+        quad_t* __restrict__ p = (quad_t*)(s0 + (size_t)slot * RLX_SLOT_WORDS * ns);
+        unsigned d[RLX_SLOT_WORDS];
+        rlx_pack(r, d);
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            unsigned d0, d1, d2;
-            rlx_pack4(r.s + 4 * j, d0, d1, d2);
-            __builtin_nontemporal_store(d0, p + (size_t)(3 * j) * ns);
-            __builtin_nontemporal_store(d1, p + (size_t)(3 * j + 1) * ns);
-            __builtin_nontemporal_store(d2, p + (size_t)(3 * j + 2) * ns);
+        for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
+            quad_t v;
+            v.x = d[4 * q4]; v.y = d[4 * q4 + 1]; v.z = d[4 * q4 + 2]; v.w = d[4 * q4 + 3];
+            __builtin_nontemporal_store(v, p + (size_t)q4 * ns);
         }
-        __builtin_nontemporal_store(r.c, p + (size_t)18 * ns);
     }
 };
 

@@ -30,10 +30,13 @@ struct RlxRegs {
 
 // Device-memory form of a stream's state: the 24 words are 24-bit integers, so four of them fit
 // three 32-bit words (the fourth one's bytes ride in the top bytes of the other three); 18 words
-// + the carry = 19 instead of 25 per state.  The state is read and written once per link update
-// (an eighth of the update pass's memory traffic in unpacked form), the handful of byte moves is
-// cheap beside that.
+// + the carry = 19 instead of 25 per state, stored as five 16-byte quads per stream (the last word
+// unused), quad q of stream i at word (q * ns + i) * 4: a wave moves a state with five 1 KiB
+// accesses.  The state is read and written once per link update (an eighth of the update pass's
+// memory traffic in unpacked form), the handful of byte moves is cheap beside that.
 constexpr int RLX_PACKED_WORDS = 19;
+constexpr int RLX_PACKED_QUADS = 5;
+constexpr int RLX_SLOT_WORDS = 4 * RLX_PACKED_QUADS;   // per stream and slot in device memory
 __host__ __device__ inline void rlx_pack4(const unsigned* s, unsigned& d0, unsigned& d1, unsigned& d2)
 {
     d0 = s[0] | (s[3] << 24);
@@ -47,6 +50,19 @@ __host__ __device__ inline void rlx_unpack4(unsigned d0, unsigned d1, unsigned d
     s[2] = d2 & 0xffffffu;
     s[3] = (d0 >> 24) | ((d1 >> 24) << 8) | ((d2 >> 24) << 16);
 }
+__host__ __device__ inline void rlx_pack(const RlxRegs& r, unsigned d[RLX_SLOT_WORDS])
+{
+    for (int j = 0; j < 6; j++) rlx_pack4(r.s + 4 * j, d[3 * j], d[3 * j + 1], d[3 * j + 2]);
+    d[18] = r.c;
+    d[19] = 0u;
+}
+__host__ __device__ inline void rlx_unpack(const unsigned d[RLX_SLOT_WORDS], RlxRegs& r)
+{
+    for (int j = 0; j < 6; j++) rlx_unpack4(d[3 * j], d[3 * j + 1], d[3 * j + 2], r.s + 4 * j);
+    r.c = d[18];
+}
+// word k of stream i's packed state inside a slot of ns streams
+inline size_t rlx_slot_index(int k, size_t ns, size_t i) { return ((size_t)(k / 4) * ns + i) * 4 + (size_t)(k % 4); }
 
 // SU(N)/random/random.cpp:192-196
 __host__ __device__ inline int rlx_nskip_for_level(int level)
