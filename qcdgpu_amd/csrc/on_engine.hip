@@ -101,9 +101,9 @@ int seed_streams(qcd_on_ctx* c)
     const int nskip = rlx_nskip_for_level(c->p.lux_level);
     const std::vector<int> seeds = stream_seeds(c->p.rand_series, 0, ns);
     const int ns_pad = cdiv(ns, ON_RLX_TILE) * ON_RLX_TILE;
-    std::vector<unsigned> st((size_t)RLX_PACKED_WORDS * ns_pad);
-    auto at = [](int w, int i) {   // [tile][packed word][lane], see RlxTileHome
-        return ((size_t)(i / ON_RLX_TILE) * RLX_PACKED_WORDS + w) * ON_RLX_TILE + i % ON_RLX_TILE;
+    std::vector<unsigned> st((size_t)RLX_SLOT_WORDS * ns_pad);
+    auto at = [](int w, int i) {   // [tile][quad][lane][4], see RlxTileHome
+        return (((size_t)(i / ON_RLX_TILE) * RLX_PACKED_QUADS + w / 4) * ON_RLX_TILE + i % ON_RLX_TILE) * 4 + w % 4;
     };
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
@@ -113,8 +113,9 @@ int seed_streams(qcd_on_ctx* c)
         for (int i = lo; i < hi; i++) {
             RlxRegs r;
             rlx_seed_state(seeds[(size_t)i], nskip, r);
-            for (int j = 0; j < 6; j++) rlx_pack4(r.s + 4 * j, st[at(3 * j, i)], st[at(3 * j + 1, i)], st[at(3 * j + 2, i)]);
-            st[at(18, i)] = r.c;
+            unsigned d[RLX_SLOT_WORDS];
+            rlx_pack(r, d);
+            for (int k = 0; k < RLX_SLOT_WORDS; k++) st[at(k, i)] = d[k];
         }
     };
     std::vector<std::thread> pool;
@@ -261,7 +262,7 @@ int qcd_on_create(qcd_on_ctx** out, const qcd_on_params* p)
     tryhip(hipEventCreate(&c->ev0), "hipEventCreate");
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
     tryhip(hipMalloc(&c->phi, (size_t)2 * g.vh * c->elem), "hipMalloc(field)");
-    const size_t st_words = (size_t)RLX_PACKED_WORDS * cdiv(g.vh, ON_RLX_TILE) * ON_RLX_TILE;
+    const size_t st_words = (size_t)RLX_SLOT_WORDS * cdiv(g.vh, ON_RLX_TILE) * ON_RLX_TILE;
     tryhip(hipMalloc(&c->rv.slot0, 2 * st_words * sizeof(unsigned)), "hipMalloc(ranlux)");
     c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + st_words : nullptr;
     tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh * sizeof(unsigned)), "hipMalloc(ranlux ctl)");

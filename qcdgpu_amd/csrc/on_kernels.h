@@ -146,36 +146,38 @@ struct RlxTileHome {
     __device__ __forceinline__ void bind(const RlxView& view, int stream)
     {
         const int tile = stream / ON_RLX_TILE;
-        s0 = view.slot0 + (size_t)tile * ON_RLX_TILE * RLX_PACKED_WORDS + (stream - tile * ON_RLX_TILE);
+        s0 = view.slot0 + ((size_t)tile * ON_RLX_TILE * RLX_PACKED_QUADS + (stream - tile * ON_RLX_TILE)) * 4;
         ctl = view.ctl + stream;
         slot_stride = (size_t)(view.slot1 - view.slot0);
         q = view.q;
         rem = view.rem;
     }
-    // packed form in memory (rlx_pack4, 19 words per state): the generator state is most of what a
-    // pass of this model moves (one 4-byte field value per site against 2 x 76 bytes of state)
+    // packed form in memory (rlx_pack: five 16-byte quads per state, quad q4 of a tile's lane at word
+    // ((tile * 5 + q4) * 256 + lane) * 4): the generator state is most of what a pass of this model
+    // moves (one 4-byte field value per site against 2 x 80 bytes of state)
+    typedef unsigned quad_t __attribute__((ext_vector_type(4)));
     __device__ __forceinline__ void load_state(RlxRegs& r, int slot) const
     {
-        const unsigned* __restrict__ p = s0 + (size_t)slot * slot_stride;
-        unsigned d[RLX_PACKED_WORDS];
+        const quad_t* __restrict__ p = (const quad_t*)(s0 + (size_t)slot * slot_stride);
+        unsigned d[RLX_SLOT_WORDS];
 #pragma unroll
-        for (int k = 0; k < RLX_PACKED_WORDS; k++) d[k] = __builtin_nontemporal_load(p + k * ON_RLX_TILE);
-#pragma unroll
-        for (int j = 0; j < 6; j++) rlx_unpack4(d[3 * j], d[3 * j + 1], d[3 * j + 2], r.s + 4 * j);
-        r.c = d[18];
+        for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
+            const quad_t v = __builtin_nontemporal_load(p + q4 * ON_RLX_TILE);
+            d[4 * q4] = v.x; d[4 * q4 + 1] = v.y; d[4 * q4 + 2] = v.z; d[4 * q4 + 3] = v.w;
+        }
+        rlx_unpack(d, r);
     }
     __device__ __forceinline__ void store_state(const RlxRegs& r, int slot) const
     {
-        unsigned* __restrict__ p = s0 + (size_t)slot * slot_stride;
+        quad_t* __restrict__ p = (quad_t*)(s0 + (size_t)slot * slot_stride);
+        unsigned d[RLX_SLOT_WORDS];
+        rlx_pack(r, d);
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            unsigned d0, d1, d2;
-            rlx_pack4(r.s + 4 * j, d0, d1, d2);
-            __builtin_nontemporal_store(d0, p + (3 * j) * ON_RLX_TILE);
-            __builtin_nontemporal_store(d1, p + (3 * j + 1) * ON_RLX_TILE);
-            __builtin_nontemporal_store(d2, p + (3 * j + 2) * ON_RLX_TILE);
+        for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
+            quad_t v;
+            v.x = d[4 * q4]; v.y = d[4 * q4 + 1]; v.z = d[4 * q4 + 2]; v.w = d[4 * q4 + 3];
+            __builtin_nontemporal_store(v, p + q4 * ON_RLX_TILE);
         }
-        __builtin_nontemporal_store(r.c, p + 18 * ON_RLX_TILE);
     }
 };
 
