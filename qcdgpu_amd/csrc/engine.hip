@@ -881,9 +881,12 @@ static int measure_profile(qcd_ctx* c, int axis, double* sums, bool polyakov)
             return fail(QCD_ERR_UNSUPPORTED, "profile of %d planes does not fit the reduction buffers", ext);
         Timed tm(c, 1);
         if (!c->loops_fresh && (rc = launch_polyakov(c, nb))) return rc;
-        hipLaunchKernelGGL((k_loops_profile<MEAS_BLOCK>), dim3(ext), dim3(MEAS_BLOCK), 0, c->stream, c->loops, g, axis, c->partial);
+        // one workgroup per plane: its pair is the plane's result and goes straight to the host's result words
+        hipLaunchKernelGGL((k_loops_profile<MEAS_BLOCK>), dim3(ext), dim3(MEAS_BLOCK), 0, c->stream, c->loops, g, axis,
+                           (double2*)c->result_host_dev);
         HIP_TRY(hipGetLastError());
-        if ((rc = reduce_partials(c, 1, ext, sums))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 2 * ext; i++) sums[i] = c->result_host[i];
         c->loops_fresh = true;
         return tm.finish();
     }
