@@ -390,7 +390,7 @@ int reduce_partials(qcd_ctx* c, int n, int nout, double* host_out)
 {
     // the reduce kernel writes the few result words straight into pinned host memory: no copy command
     // between the kernel and the synchronisation (about 10 us per measurement call)
-    hipLaunchKernelGGL((k_reduce<MEAS_BLOCK>), dim3(1), dim3(MEAS_BLOCK), 0, c->stream, c->partial, n, nout, c->result_host_dev);
+    hipLaunchKernelGGL((k_reduce<MEAS_BLOCK>), dim3(nout), dim3(MEAS_BLOCK), 0, c->stream, c->partial, n, c->result_host_dev);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2 * nout; i++) host_out[i] = c->result_host[i];

@@ -1130,34 +1130,35 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
     block_reduce_store<BLOCK>(spat, temp, partial);
 }
 
-// sums n double2 partials per output pair in index order (one block): out[2*o], out[2*o+1]
+// sums n double2 partials per output pair in a fixed order (strided, then a tree); workgroup o
+// does output pair o: out[2*o], out[2*o+1].  (One workgroup looping over the outputs took 30 us for
+// the 32 planes of a profile.  Folding this into the measurement kernels -- the workgroup that
+// finishes last adds up -- was tried and is worse: the device-scope fences it needs write back and
+// invalidate the XCDs' L2s, plaquette call 200 -> 390 us.)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_reduce(const double2* __restrict__ partial, const int n, const int nout,
-                                                  double* __restrict__ out)
+__global__ __launch_bounds__(BLOCK) void k_reduce(const double2* __restrict__ partial, const int n, double* __restrict__ out)
 {
     __shared__ double sa[BLOCK], sb[BLOCK];
-    for (int o = 0; o < nout; o++) {
-        double a = 0.0, b = 0.0;
-        for (int i = threadIdx.x; i < n; i += BLOCK) {
-            const double2 p = partial[(size_t)o * n + i];
-            a += p.x;
-            b += p.y;
-        }
-        sa[threadIdx.x] = a;
-        sb[threadIdx.x] = b;
-        __syncthreads();
-        for (int s = BLOCK / 2; s > 0; s >>= 1) {
-            if (threadIdx.x < s) {
-                sa[threadIdx.x] += sa[threadIdx.x + s];
-                sb[threadIdx.x] += sb[threadIdx.x + s];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            out[2 * o] = sa[0];
-            out[2 * o + 1] = sb[0];
+    const int o = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        const double2 p = partial[(size_t)o * n + i];
+        a += p.x;
+        b += p.y;
+    }
+    sa[threadIdx.x] = a;
+    sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sa[threadIdx.x] += sa[threadIdx.x + s];
+            sb[threadIdx.x] += sb[threadIdx.x + s];
         }
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[2 * o] = sa[0];
+        out[2 * o + 1] = sb[0];
     }
 }
 
