@@ -52,6 +52,7 @@ int fail(int code, const char* fmt, ...)
 constexpr int UPD_BLOCK = QCD_UPD_BLOCK;
 constexpr int REDO_BLOCK = 64, REDO_GRID = 128;
 constexpr int MEAS_BLOCK = 256;
+constexpr size_t DRAWS_BYTES = (size_t)DRAW_SLOTS * DRAW_SLOT_STRIDE * sizeof(unsigned long long);
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
@@ -88,8 +89,8 @@ struct qcd_ctx {
     int result_len;           // doubles in result_host
     double* result_host;      // pinned, coherent
     double* result_host_dev;  // the same memory as the device addresses it
-    unsigned long long* draws_dev;
-    unsigned long long* draws_host;  // pinned
+    unsigned long long* draws_dev;   // DRAW_SLOTS partial counts, DRAW_SLOT_STRIDE elements apart
+    unsigned long long* draws_host;  // pinned, same shape
     int* redo_list;           // update pass: sites left to the general random stream
     unsigned* redo_count;     // two counters, used by alternate passes (a second pair for the side lane)
     unsigned pass_no;
@@ -362,7 +363,7 @@ int seed_streams(qcd_ctx* c)
     HIP_TRY(hipMemcpyAsync(c->rv.slot0, st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->rv.slot1, 0, st.size() * sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(c->rv.ctl, 0, (size_t)ns * sizeof(unsigned), c->stream));
-    HIP_TRY(hipMemsetAsync(c->draws_dev, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->draws_dev, 0, DRAWS_BYTES, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->rv.q = nskip / 24;
     c->rv.rem = nskip % 24;
@@ -383,6 +384,17 @@ int check_ctx(qcd_ctx* c, bool need_init, bool join = true, bool reads_links = f
         HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev, 0));
         c->side_pending = false;
     }
+    return QCD_OK;
+}
+
+// total of the partial draw counts
+int read_draws(qcd_ctx* c, unsigned long long* total)
+{
+    HIP_TRY(hipMemcpyAsync(c->draws_host, c->draws_dev, DRAWS_BYTES, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long t = 0;
+    for (int k = 0; k < DRAW_SLOTS; k++) t += c->draws_host[(size_t)k * DRAW_SLOT_STRIDE];
+    *total = t;
     return QCD_OK;
 }
 
@@ -538,7 +550,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipMalloc(&c->loops, (size_t)g.nx * g.ny * g.nz * sizeof(double2)), "hipMalloc(polyakov loops)");
     tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(result)");
     if (rc == QCD_OK) tryhip(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0), "hipHostGetDevicePointer(result)");
-    tryhip(hipMalloc(&c->draws_dev, sizeof(unsigned long long)), "hipMalloc(draws)");
+    tryhip(hipMalloc(&c->draws_dev, DRAWS_BYTES), "hipMalloc(draws)");
     tryhip(hipMalloc(&c->redo_list, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list)");
     tryhip(hipMalloc(&c->redo_count, 4 * sizeof(unsigned)), "hipMalloc(redo count)");
     if (rc == QCD_OK) tryhip(hipMemset(c->redo_count, 0, 4 * sizeof(unsigned)), "hipMemset(redo count)");
@@ -548,7 +560,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
         tryhip(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming), "hipEventCreate");
         tryhip(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming), "hipEventCreate");
     }
-    tryhip(hipHostMalloc(&c->draws_host, sizeof(unsigned long long)), "hipHostMalloc(draws)");
+    tryhip(hipHostMalloc(&c->draws_host, DRAWS_BYTES), "hipHostMalloc(draws)");
     if (rc != QCD_OK) {
         qcd_destroy(c);
         return rc;
@@ -1021,7 +1033,14 @@ static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
     auto cp = [&](void* dev, void* hp, size_t n) -> hipError_t {
         return up ? hipMemcpyAsync(dev, hp, n, kind, c->stream) : hipMemcpyAsync(hp, dev, n, kind, c->stream);
     };
-    HIP_TRY(cp(c->draws_dev, h, sizeof(unsigned long long)));
+    if (up) {   // the saved total goes into the first partial count
+        HIP_TRY(hipMemsetAsync(c->draws_dev, 0, DRAWS_BYTES, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->draws_dev, h, sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    } else {
+        unsigned long long total = 0;
+        if ((rc = read_draws(c, &total))) return rc;
+        memcpy(h, &total, sizeof(total));
+    }
     h += sizeof(unsigned long long);
     HIP_TRY(cp(c->rv.ctl, h, ns * sizeof(unsigned)));
     h += ns * sizeof(unsigned);
@@ -1196,10 +1215,7 @@ int qcd_rng_draws(qcd_ctx* c, unsigned long long* draws)
     int rc = check_ctx(c, true);
     if (rc) return rc;
     if (!draws) return fail(QCD_ERR_INVALID, "null output");
-    HIP_TRY(hipMemcpyAsync(c->draws_host, c->draws_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    *draws = *c->draws_host;
-    return QCD_OK;
+    return read_draws(c, draws);
 }
 
 // ---- host-only helpers exported for the CPU test-suite (no device needed) -------------------

@@ -785,6 +785,11 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 // everything an update launch needs, as ONE kernel argument: the kernel re-reads it from the
 // kernel-argument segment at the start of every trip of its loop (scalar loads), so that no
 // argument and nothing derived from one has to stay in registers from one site to the next
+// the count of random numbers drawn is kept as DRAW_SLOTS partial counts (element k * DRAW_SLOT_STRIDE);
+// their sum is the count
+constexpr int DRAW_SLOTS = 64;
+constexpr int DRAW_SLOT_STRIDE = 16;   // 128 bytes
+
 struct UpdArgs {
     double2* U;
     Geom g;
@@ -918,7 +923,9 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     }
     if (!GID) {
         used = block_sum_u64<BLOCK>(used);
-        if ((threadIdx.x & 63) == 0 && used) atomicAdd(args_by_value.draws, used);
+        // one of DRAW_SLOTS counters, a cache line apart: atomics on one address are done one after
+        // the other in the L2, and every wave of the launch arrives here at about the same time
+        if ((threadIdx.x & 63) == 0 && used) atomicAdd(args_by_value.draws + (size_t)(blockIdx.x % DRAW_SLOTS) * DRAW_SLOT_STRIDE, used);
     }
 #endif
 }
