@@ -170,8 +170,9 @@ int qcd_download(qcd_ctx *ctx, void *host_table, size_t bytes, int rowsize);
 /* generator part of lattice_save_state / lattice_load_state (suncl.cpp:1857-2079).  The reference
  * restores its generator by replaying PRNG0->produce() PRNG_counter times (suncl.cpp:5349-5351);
  * per-thread streams are saved instead: [draws u64][ctl ns][slot0 25*ns][slot1 25*ns], 32-bit
- * words, ns = owned half-sites, the slots in word-major order [w][stream].  Upload after
- * qcd_upload or qcd_init_lattice. */
+ * words, ns = owned half-sites, the slots in word-major order [w][stream] (24 words of 24 bits and
+ * the carry; the device keeps them packed, these calls convert).  Upload after qcd_upload or
+ * qcd_init_lattice. */
 size_t qcd_rng_state_bytes(const qcd_ctx *ctx);
 int qcd_rng_state_download(qcd_ctx *ctx, void *host, size_t bytes);
 int qcd_rng_state_upload(qcd_ctx *ctx, const void *host, size_t bytes);
