@@ -51,7 +51,10 @@ int fail(int code, const char* fmt, ...)
 #endif
 constexpr int UPD_BLOCK = QCD_UPD_BLOCK;
 constexpr int REDO_BLOCK = 64, REDO_GRID = 128;
-constexpr int MEAS_BLOCK = 256;
+#ifndef QCD_MEAS_BLOCK
+#define QCD_MEAS_BLOCK 256
+#endif
+constexpr int MEAS_BLOCK = QCD_MEAS_BLOCK;   // threads per workgroup of the measurement kernels
 constexpr size_t DRAWS_BYTES = (size_t)DRAW_SLOTS * DRAW_SLOT_STRIDE * sizeof(unsigned long long);
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
