@@ -130,6 +130,7 @@ def _load():
     lib.qcd_on_download.argtypes = [P, C.c_void_p, C.c_size_t]
     lib.qcd_host_gid_link.argtypes = [I, I, I, I, pd]
     lib.qcd_host_gid_randoms.argtypes = [I, I, I, C.POINTER(C.c_float)]
+    lib.qcd_host_rlx_pack_check.argtypes = [C.c_uint, I, C.POINTER(C.c_uint)]
     return lib
 
 
@@ -343,6 +344,13 @@ def host_gid_randoms(gid, nhit, sites):
     r = (C.c_float * 6)()
     _check(lib.qcd_host_gid_randoms(gid, nhit, sites, r))
     return np.array(r[:], dtype=np.float32)
+
+
+def host_rlx_pack_check(seed, n):
+    """Generator states that do not survive the device's packed form (must be 0)."""
+    bad = C.c_uint(0)
+    _check(lib.qcd_host_rlx_pack_check(seed, n, C.byref(bad)))
+    return bad.value
 
 
 # defaults of the reference's O(N) main (O(N)/QCDGPU.cpp:121-128)

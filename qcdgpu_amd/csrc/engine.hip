@@ -1369,6 +1369,28 @@ int qcd_host_gid_randoms(int gid, int nhit, int sites, float out[6])
     return QCD_OK;
 }
 
+// packs and unpacks n pseudo-random generator states (every word below 2^24, carry 0 or 1) the way the
+// device keeps them; *errors = states that did not survive, or whose packed form is not 19 words
+int qcd_host_rlx_pack_check(unsigned seed, int n, unsigned* errors)
+{
+    if (!errors) return fail(QCD_ERR_INVALID, "null output");
+    unsigned x = seed | 1u, bad = 0;
+    auto next = [&x]() { x = x * 1664525u + 1013904223u; return x >> 8; };   // 24 bits
+    for (int i = 0; i < n; i++) {
+        RlxRegs r, t;
+        for (int w = 0; w < 24; w++) r.s[w] = (i == 0) ? 0xffffffu : (i == 1 ? 0u : next());
+        r.c = next() & 1u;
+        unsigned d[RLX_SLOT_WORDS];
+        rlx_pack(r, d);
+        rlx_unpack(d, t);
+        bool ok = t.c == r.c && d[RLX_PACKED_WORDS] == 0u;
+        for (int w = 0; w < 24; w++) ok = ok && t.s[w] == r.s[w];
+        if (!ok) bad++;
+    }
+    *errors = bad;
+    return QCD_OK;
+}
+
 }  // extern "C"
 
 #ifdef QCD_TRACE

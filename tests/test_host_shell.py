@@ -117,6 +117,13 @@ def test_odd_extents_are_refused_before_any_device_work():
             q.OnContext(L=L)
 
 
+def test_packed_generator_state_round_trips():
+    """The device keeps a RANLUX state as 19 words (24-bit words four in three); the checkpoint
+    format has 25.  All-ones, all-zero and 100000 pseudo-random states survive pack + unpack."""
+    import qcdgpu_amd as q
+    assert q.capi.host_rlx_pack_check(12345, 100000) == 0
+
+
 def test_ranlux_batch_formulation_equals_reference_generator():
     import qcdgpu_amd as q
     for lux, nskip in enumerate((24, 48, 97, 223, 389)):
