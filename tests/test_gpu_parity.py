@@ -389,3 +389,31 @@ def test_su2_observables_match_reference_cpu_remeasurement(fname):
     assert w == pytest.approx(e["Wilson_loop"], rel=1e-11)
     want = np.array([e["F_%s_%s_%s" % (p, a, k)] for a in ("3", "8") for p in "abc" for k in ("re", "im")])
     assert np.allclose(f, want, rtol=1e-10, atol=1e-14)
+
+
+def _binned(x, nbins):
+    x = np.asarray(x, dtype=float)
+    b = x[: len(x) // nbins * nbins].reshape(nbins, -1).mean(axis=1)
+    return x.mean(), b.std(ddof=1) / np.sqrt(nbins)
+
+
+@pytest.mark.parametrize("fname,group", [("stat_su3_8x8x8x8_b6.json", 3), ("stat_su2_8x8x8x8_b2.5.json", 2)])
+def test_mean_plaquette_agrees_with_reference_chain(fname, group):
+    """Statistical leg: the reference's own program (one random stream, sequential order) and this
+    engine (one stream per thread) run different Markov chains of the same measure, so the mean
+    plaquette after thermalisation must agree within errors.  8^4, 100 thermalisation sweeps,
+    1200 reference samples against 2000 here; errors from 20 resp. 25 bins; tolerance 4 sigma."""
+    import qcdgpu_amd as q
+    fx = ol.golden(fname)
+    a = fx["init"]
+    with q.Context(group=group, L=(8, 8, 8, 8), beta=a["BETA"], nhit=a["NHIT"], rand_series=a["RANDSERIES"]) as c:
+        c.init_lattice()
+        c.sweep(a["NAV"])
+        mine = []
+        for _ in range(2000):
+            c.sweep(1)
+            mine.append(c.plaquette()[2])
+    m_ref, e_ref = _binned(fx["plq_total"], 20)
+    m_gpu, e_gpu = _binned(mine, 25)
+    assert abs(m_ref - m_gpu) < 4.0 * np.hypot(e_ref, e_gpu), (m_ref, e_ref, m_gpu, e_gpu)
+    assert e_gpu < 1e-3 and e_ref < 1e-3

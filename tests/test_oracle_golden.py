@@ -302,3 +302,26 @@ def test_su2_polyakov_wilson_match_reference_cpu_code(fname):
     f = lat.fmunu_sums(doc["field"] - 1, doc["index1"], doc["index2"]) / np.prod(doc["L"])
     assert np.allclose(f, expected_fmunu(doc), rtol=1e-11, atol=1e-15)
     lat.close()
+
+
+def test_persite_streams_sample_the_same_measure_as_the_reference_chain():
+    """The checker's per-thread-stream mode (what the GPU engine does) against the reference
+    program's single-stream chain: SU(2) 8^4 beta = 2.5, mean plaquette after 100 thermalisation
+    sweeps, 300 samples here against the fixture's 1200, binned errors, 4 sigma."""
+    fx = ol.golden("stat_su2_8x8x8x8_b2.5.json")
+    a = fx["init"]
+    lat = ol.Lattice(2, (8, 8, 8, 8), a["BETA"], nhit=a["NHIT"], ints=1, rng_mode=ol.RNG_PERSITE)
+    lat.sweep(a["NAV"])
+    mine = []
+    for _ in range(300):
+        lat.sweep(1)
+        mine.append(lat.plaquette()[2])
+    lat.close()
+
+    def binned(x, nbins):
+        x = np.asarray(x, dtype=float)
+        b = x[: len(x) // nbins * nbins].reshape(nbins, -1).mean(axis=1)
+        return x.mean(), b.std(ddof=1) / np.sqrt(nbins)
+    m_ref, e_ref = binned(fx["plq_total"], 20)
+    m_own, e_own = binned(mine, 15)
+    assert abs(m_ref - m_own) < 4.0 * np.hypot(e_ref, e_own), (m_ref, e_ref, m_own, e_own)
