@@ -417,3 +417,27 @@ def test_mean_plaquette_agrees_with_reference_chain(fname, group):
     m_gpu, e_gpu = _binned(mine, 25)
     assert abs(m_ref - m_gpu) < 4.0 * np.hypot(e_ref, e_gpu), (m_ref, e_ref, m_gpu, e_gpu)
     assert e_gpu < 1e-3 and e_ref < 1e-3
+
+
+@pytest.mark.parametrize("fname,group", [("stat_su3_8x8x8x8_b6.json", 3), ("stat_su2_8x8x8x8_b2.5.json", 2)])
+def test_overrelaxation_leaves_the_measure_alone(fname, group):
+    """Overrelaxation has no counterpart in the reference (parity unpinned).  Beyond its defining
+    property (action unchanged link by link, tested elsewhere) a chain of one heat-bath sweep and two
+    overrelaxation sweeps per sample must give the reference chain's mean plaquette."""
+    import qcdgpu_amd as q
+    fx = ol.golden(fname)
+    a = fx["init"]
+    with q.Context(group=group, L=(8, 8, 8, 8), beta=a["BETA"], nhit=a["NHIT"], rand_series=77) as c:
+        c.init_lattice()
+        for _ in range(50):
+            c.sweep(1)
+            c.overrelax_sweep(2)
+        mine = []
+        for _ in range(1500):
+            c.sweep(1)
+            c.overrelax_sweep(2)
+            mine.append(c.plaquette()[2])
+    m_ref, e_ref = _binned(fx["plq_total"], 20)
+    m_gpu, e_gpu = _binned(mine, 25)
+    assert abs(m_ref - m_gpu) < 4.0 * np.hypot(e_ref, e_gpu), (m_ref, e_ref, m_gpu, e_gpu)
+    assert e_gpu < 1e-3
