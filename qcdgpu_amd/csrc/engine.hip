@@ -81,6 +81,7 @@ struct qcd_ctx {
     double2* U;
     size_t U_elems;
     RlxView rv;
+    unsigned char* slice_slot;   // per owned x-slice: the slot its streams' states are in (see RlxView::cur)
     float* gidr;
     double2* partial;
     int npartial;
@@ -171,6 +172,16 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.beta_eff = beta_eff;
     a.beta_inv = 1.0 / beta_eff;
     a.rv = c->rv;
+    if (!GID) {
+        // the slices of the range must all have been through the same number of passes
+        const int s0 = c->slice_slot[xs_begin % g.nx];
+        for (int k = 1; k < xs_count; k++)
+            if (c->slice_slot[(xs_begin + k) % g.nx] != s0)
+                return fail(QCD_ERR_STATE, "update of slices %d..%d: some of them have been updated one pass more often than others", xs_begin,
+                            xs_begin + xs_count - 1);
+        a.rv.cur = s0;
+        for (int k = 0; k < xs_count; k++) c->slice_slot[(xs_begin + k) % g.nx] ^= 1;
+    }
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
@@ -365,7 +376,7 @@ int seed_streams(qcd_ctx* c)
     }
     HIP_TRY(hipMemcpyAsync(c->rv.slot0, st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->rv.slot1, 0, st.size() * sizeof(unsigned), c->stream));
-    HIP_TRY(hipMemsetAsync(c->rv.ctl, 0, (size_t)ns * sizeof(unsigned), c->stream));
+    memset(c->slice_slot, 0, (size_t)g.nx);
     HIP_TRY(hipMemsetAsync(c->draws_dev, 0, DRAWS_BYTES, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->rv.q = nskip / 24;
@@ -541,7 +552,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     const size_t stw = (size_t)RLX_SLOT_WORDS * g.vh_int * sizeof(unsigned);
     tryhip(hipMalloc(&c->rv.slot0, 2 * stw), "hipMalloc(ranlux)");   // both slots, back to back
     c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_SLOT_WORDS * g.vh_int : nullptr;
-    tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh_int * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
+    c->slice_slot = (unsigned char*)calloc((size_t)g.nx, 1);
+    if (!c->slice_slot && rc == QCD_OK) rc = fail(QCD_ERR_NOMEM, "calloc(slice slots)");
     c->rv.ns = g.vh_int;
     if (p->start_mode == QCD_START_GID)
         tryhip(hipMalloc(&c->gidr, (size_t)6 * g.nx * g.gslice * sizeof(float)), "hipMalloc(gid table)");
@@ -579,7 +591,7 @@ void qcd_destroy(qcd_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->U);
     (void)hipFree(c->rv.slot0);
-    (void)hipFree(c->rv.ctl);
+    free(c->slice_slot);
     (void)hipFree(c->gidr);
     (void)hipFree(c->edge_buf);
     if (c->edge_ev) (void)hipEventDestroy(c->edge_ev);
@@ -1045,15 +1057,21 @@ static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
         memcpy(h, &total, sizeof(total));
     }
     h += sizeof(unsigned long long);
-    HIP_TRY(cp(c->rv.ctl, h, ns * sizeof(unsigned)));
+    // control words: which of a stream's two slots holds its state in front of the next batch.  The
+    // device has no such words (all streams of an x-slice are in the same slot, slice_slot): written
+    // from that on the way out; on the way in each stream's current state goes to slot 0
+    unsigned* ctlw = (unsigned*)h;
+    if (!up)
+        for (size_t i = 0; i < ns; i++) ctlw[i] = c->slice_slot[i / (size_t)c->g.slice_h];
     h += ns * sizeof(unsigned);
     std::vector<unsigned> packed((size_t)2 * RLX_SLOT_WORDS * ns);   // both slots, as on the device
     unsigned* wide = (unsigned*)h;                                   // [slot][w][stream], w in [0, 25)
     auto convert = [&](bool pack) {
         for (int slot = 0; slot < 2; slot++) {
-            unsigned* pk = packed.data() + (size_t)slot * RLX_SLOT_WORDS * ns;
             unsigned* wd = wide + (size_t)slot * RLX_STATE_WORDS * ns;
             for (size_t i = 0; i < ns; i++) {
+                const int dev_slot = pack ? (slot ^ (int)(ctlw[i] & 1u)) : slot;
+                unsigned* pk = packed.data() + (size_t)dev_slot * RLX_SLOT_WORDS * ns;
                 RlxRegs r;
                 unsigned d[RLX_SLOT_WORDS];
                 if (pack) {
@@ -1070,7 +1088,10 @@ static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
             }
         }
     };
-    if (up) convert(true);
+    if (up) {
+        convert(true);
+        memset(c->slice_slot, 0, (size_t)c->g.nx);
+    }
     HIP_TRY(cp(c->rv.slot0, packed.data(), packed.size() * sizeof(unsigned)));   // slot1 follows slot0 in one allocation
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!up) convert(false);

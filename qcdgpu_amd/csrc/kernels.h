@@ -36,7 +36,11 @@ constexpr int RLX_WINDOW = 2;
 struct RlxView {
     unsigned* slot0;    // packed generator state in front of a batch: quad q of a stream at word (q * ns + stream) * 4
     unsigned* slot1;    // second copy = slot0 + 20*ns (one allocation); ctl says which of the two is current
-    unsigned* ctl;      // bit 0: slot that holds the state in front of the stream's next batch
+    unsigned* ctl;      // (scalar model's engine only) bit 0: slot that holds the state in front of a stream's next batch
+    int cur;            // link update: the slot that holds EVERY stream's state in front of its next batch.  A pass
+                        // uses each stream once and always leaves its state in the other slot, so the slot is
+                        // known per launch and costs no memory access (a per-stream control word did: its load
+                        // and store made the 32^4 pass 11 % slower)
     int ns;             // streams
     int q, rem;         // nskip = 24*q + rem
 };
@@ -44,13 +48,11 @@ struct RlxView {
 // Where a stream's persistent state lives, and the moves both stream types share.
 struct RlxHome {
     unsigned* __restrict__ s0;   // this stream's first quad in slot 0; slot 1 lies 20*ns words behind it
-    unsigned* __restrict__ ctl;
     int ns, q, rem;
 
     __device__ __forceinline__ void bind(const RlxView& view, int stream)
     {
         s0 = view.slot0 + (size_t)4 * stream;
-        ctl = view.ctl + stream;
         ns = view.ns;
         q = view.q;
         rem = view.rem;
@@ -102,16 +104,16 @@ struct RlxFast {
     int pos, cur;
     bool dry;
 
-    // The three steps of opening the stream, separate so that the kernel can place the two
-    // rounds of loads (control word, then state) under other work:
-    // attach: bind the stream and request its control word
+    // The three steps of opening the stream, separate so that the kernel can place the state's
+    // loads under other work:
+    // attach: bind the stream
     __device__ __forceinline__ void attach(const RlxView& view, int stream, float* lds_column)
     {
         h.bind(view, stream);
         buf = lds_column;
         dry = false;
         pos = 0;
-        cur = (int)(*h.ctl & 1u);
+        cur = view.cur;
     }
     // fetch: request the generator state in front of the stream's next batch
     __device__ __forceinline__ void fetch(RlxRegs& r) const
@@ -162,15 +164,14 @@ struct RlxFast {
     {
         if (dry) return -1;
         if (pos > 24) {
-            // rare (two or more rejected trials): the second batch was touched, the stream
-            // resumes in front of the third; rebuild that state from the one in front of the second
+            // rare (two or more rejected trials): the second batch was touched, the stream resumes in
+            // front of the third; rebuild that state from the one in front of the second, in place
+            // (every stream leaves a pass with its state in slot cur ^ 1)
             RlxRegs r;
             h.load_state(r, cur ^ 1);
             rlx_round(r);
             skip(r);
-            h.store_state(r, cur);
-        } else {
-            *h.ctl = (unsigned)(cur ^ 1);
+            h.store_state(r, cur ^ 1);
         }
         return pos;
     }
@@ -191,7 +192,7 @@ struct RlxStream {
         h.bind(view, stream);
         buf = lds_column;
         pos = 0;
-        cur = (int)(*h.ctl & 1u);
+        cur = view.cur;
 #ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
         nb = 1000;
         return;
@@ -242,14 +243,15 @@ struct RlxStream {
     __device__ __forceinline__ int close()
     {
 #ifndef QCD_ABL_RNG
-        // the stream resumes in front of the batch after the last one touched
+        // the stream resumes in front of the batch after the last one touched; like every stream it
+        // leaves the pass with that state in slot cur ^ 1
         const int m = (pos - 1) / 24;
-        if (m == nb - 1) {
-            RlxRegs r;
-            advance(r);
-            *h.ctl = (unsigned)(cur ^ (nb & 1));
-        } else {
-            *h.ctl = (unsigned)(cur ^ ((m + 1) & 1));
+        RlxRegs r;
+        if (m == nb - 1) advance(r);
+        const int at = cur ^ ((m + 1) & 1);   // slot the state in front of batch m + 1 is in
+        if (at == cur) {
+            h.load_state(r, cur);
+            h.store_state(r, cur ^ 1);
         }
 #endif
         return pos;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     const int nhit = ap->nhit;
     const double beta_eff = ap->beta_eff;
     RlxView rv;
-    rv.slot0 = ap->rv.slot0; rv.slot1 = ap->rv.slot1; rv.ctl = ap->rv.ctl;
+    rv.slot0 = ap->rv.slot0; rv.slot1 = ap->rv.slot1; rv.ctl = nullptr; rv.cur = ap->rv.cur;
     rv.ns = ap->rv.ns; rv.q = ap->rv.q; rv.rem = ap->rv.rem;
     const float* __restrict__ gidr = ap->gidr;
     Site x;
@@ -862,8 +864,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
 #endif
         mat<GROUP> A, Ul;
         if constexpr (GROUP == 3) {
-            // the stream's control word is requested first, so that its state can be requested
-            // without a second round trip as soon as the staple's registers are free (requesting
+            // the stream's state is requested as soon as the staple's registers are free (requesting
             // state and link under the last staple term costs 40 registers and gains nothing)
             if (!GID) rs.attach(rv, t, rbuf + threadIdx.x);
             __builtin_amdgcn_s_setprio(QCD_PRIO_MEM);
@@ -1493,7 +1494,7 @@ __global__ __launch_bounds__(BLOCK) void k_init_hot(double2* __restrict__ U, con
         const bool even_first = (s0.y & 1) == 0;       // site 2h is the one with even y
         RlxHome home;
         home.bind(rv, t);
-        const int cur = (int)(*home.ctl & 1u);
+        const int cur = rv.cur;
         RlxRegs r;
         home.load_state(r, cur);
         float* col = rbuf + threadIdx.x;
@@ -1507,7 +1508,7 @@ __global__ __launch_bounds__(BLOCK) void k_init_hot(double2* __restrict__ U, con
             store_link(U, g, dir, 1, h, even_first ? b : a);
             used += 2 * PER_LINK;
         }
-        home.store_state(r, cur);   // in front of the stream's next batch; the control word stays
+        home.store_state(r, cur);   // in front of the stream's next batch, in the same slot: no pass has used it
     }
     used = block_sum_u64<BLOCK>(used);
     if ((threadIdx.x & 63) == 0 && used) atomicAdd(draws, used);
