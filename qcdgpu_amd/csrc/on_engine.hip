@@ -127,7 +127,8 @@ int seed_streams(qcd_on_ctx* c)
     for (auto& t : pool) t.join();
     HIP_TRY(hipMemcpyAsync(c->rv.slot0, st.data(), st.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->rv.slot1, 0, st.size() * sizeof(unsigned), c->stream));
-    HIP_TRY(hipMemsetAsync(c->rv.ctl, 0, (size_t)ns * sizeof(unsigned), c->stream));
+    c->rv.cur = 0;
+    c->rv.ctl = nullptr;
     HIP_TRY(hipMemsetAsync(c->counters, 0, 3 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->rv.q = nskip / 24;
@@ -146,6 +147,7 @@ int launch_update(qcd_on_ctx* c, int parity)
         hipLaunchKernelGGL((k_on_update<F, ON_BLOCK, 0>), grid, block, 0, c->stream, (F*)c->phi, c->g, parity,
                            params_of<F>(c), c->p.nhit, c->rv, c->wg_counts);
     HIP_TRY(hipGetLastError());
+    c->rv.cur ^= 1;   // every stream was used once and left its state in the other slot
     hipLaunchKernelGGL((k_on_count<1024>), dim3(1), dim3(1024), 0, c->stream, c->wg_counts, (int)grid.x, parity, c->counters);
     HIP_TRY(hipGetLastError());
     return QCD_OK;
@@ -265,7 +267,6 @@ int qcd_on_create(qcd_on_ctx** out, const qcd_on_params* p)
     const size_t st_words = (size_t)RLX_SLOT_WORDS * cdiv(g.vh, ON_RLX_TILE) * ON_RLX_TILE;
     tryhip(hipMalloc(&c->rv.slot0, 2 * st_words * sizeof(unsigned)), "hipMalloc(ranlux)");
     c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + st_words : nullptr;
-    tryhip(hipMalloc(&c->rv.ctl, (size_t)g.vh * sizeof(unsigned)), "hipMalloc(ranlux ctl)");
     c->rv.ns = g.vh;
     tryhip(hipMalloc(&c->counters, 3 * sizeof(unsigned long long)), "hipMalloc(counters)");
     tryhip(hipMalloc(&c->wg_counts, (size_t)2 * cdiv(g.vh, ON_BLOCK) * sizeof(unsigned long long)), "hipMalloc(workgroup counters)");
@@ -287,7 +288,6 @@ void qcd_on_destroy(qcd_on_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->phi);
     (void)hipFree(c->rv.slot0);
-    (void)hipFree(c->rv.ctl);
     (void)hipFree(c->counters);
     (void)hipFree(c->wg_counts);
     (void)hipFree(c->partial);
@@ -312,7 +312,8 @@ int qcd_on_init_lattice(qcd_on_ctx* c)
     else
         hipLaunchKernelGGL((k_on_init<float, ON_BLOCK>), grid, block, 0, c->stream, (float*)c->phi, c->g, hot, (float)c->max_U, c->rv);
     HIP_TRY(hipGetLastError());
-    if (hot) {   // two quads per thread
+    if (hot) {   // two quads per thread: one batch taken from every stream
+        c->rv.cur ^= 1;
         const unsigned long long drawn = 8ull * (unsigned long long)c->g.vh;
         HIP_TRY(hipMemcpyAsync(c->counters, &drawn, sizeof(drawn), hipMemcpyHostToDevice, c->stream));
     }

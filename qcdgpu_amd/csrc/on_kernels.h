@@ -139,7 +139,6 @@ constexpr int ON_RLX_TILE = 256;
 
 struct RlxTileHome {
     unsigned* __restrict__ s0;   // this stream's lane in word 0 of its tile, slot 0
-    unsigned* __restrict__ ctl;
     size_t slot_stride;          // words from slot 0 to slot 1
     int q, rem;
 
@@ -147,7 +146,6 @@ struct RlxTileHome {
     {
         const int tile = stream / ON_RLX_TILE;
         s0 = view.slot0 + ((size_t)tile * ON_RLX_TILE * RLX_PACKED_QUADS + (stream - tile * ON_RLX_TILE)) * 4;
-        ctl = view.ctl + stream;
         slot_stride = (size_t)(view.slot1 - view.slot0);
         q = view.q;
         rem = view.rem;
@@ -209,7 +207,7 @@ struct RlxOne {
     {
         h.bind(view, stream);
         buf = lds_column;
-        cur = (int)(*h.ctl & 1u);
+        cur = view.cur;   // the slot every stream's state is in for this launch (no per-stream control word)
         nb = 0;
         deliver();
     }
@@ -220,8 +218,19 @@ struct RlxOne {
         for (int k = 0; k < 4; k++) r[k] = buf[(pos + k) * BLOCK];
         pos += 4;
     }
-    // the stream resumes in front of the batch after the last one delivered
-    __device__ __forceinline__ void close() { *h.ctl = (unsigned)(cur ^ (nb & 1)); }
+    // the stream resumes in front of the batch after the last one delivered; every stream leaves a
+    // launch with that state in slot cur ^ 1 (an even number of deliveries, NHIT > 12 only, ends in
+    // slot cur: moved over)
+    __device__ __forceinline__ void close()
+    {
+        if ((nb & 1) == 0) move_over();
+    }
+    __device__ __noinline__ void move_over()   // cold: kept out of line so that it costs the pass no registers
+    {
+        RlxRegs r;
+        h.load_state(r, cur);
+        h.store_state(r, cur ^ 1);
+    }
 };
 
 template <int BLOCK>
