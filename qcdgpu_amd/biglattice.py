@@ -203,7 +203,7 @@ class BigLattice:
     # slice per side is enough then.  Engines with update_range only run them one after the other,
     # and the first launch gets more slices (at most a quarter of the slab per side) so that it
     # keeps the device busy.  Measured on one MI355X, 32^4 slab, messages copied device to device:
-    # 179 us per pass unsplit, 204 us split into consecutive launches 8 deep, 191 us as two
+    # 145 us per pass unsplit, 156 us split into consecutive launches 8 deep, 150 us as two
     # concurrent launches with one slice per side.
     BOUNDARY_DEPTH = 8
     BOUNDARY_DEPTH_CONCURRENT = 1
