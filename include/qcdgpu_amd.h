@@ -95,7 +95,9 @@ int qcd_sweep(qcd_ctx *ctx, int n);
 /* qcd_update restricted to xs_count owned x-slices starting at xs_begin (wrapping around the owned
  * range).  No counterpart in the reference, which updates a part as a whole and then copies its
  * edges (suncl.cpp:5026-5138): a slab updates its boundary slices first and sends them while the
- * interior is being updated.  The ranges of one pass must tile the slab exactly once. */
+ * interior is being updated.  The ranges of one pass must tile the slab exactly once: a range whose
+ * slices have been through different numbers of passes is refused (QCD_ERR_STATE), because all random
+ * streams of a launch are read from the same one of their two state slots. */
 int qcd_update_range(qcd_ctx *ctx, int parity, int dir, int xs_begin, int xs_count);
 
 /* One pass in two concurrent launches: the owned slices [first_begin, first_begin + first_count)
