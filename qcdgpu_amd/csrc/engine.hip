@@ -236,15 +236,17 @@ int launch_update(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count, b
     const bool gid = (c->p.start_mode == QCD_START_GID);
     const bool lux3 = (c->p.lux_level == 3);
     Timed tm(c, 0);
+    int rc;
     if (c->p.group == 3) {
-        if (gid) launch_update_dir<3, true, 0>(c, parity, dir, xs_begin, xs_count, side);
-        else if (lux3) launch_update_dir<3, false, 223>(c, parity, dir, xs_begin, xs_count, side);
-        else launch_update_dir<3, false, 0>(c, parity, dir, xs_begin, xs_count, side);
+        if (gid) rc = launch_update_dir<3, true, 0>(c, parity, dir, xs_begin, xs_count, side);
+        else if (lux3) rc = launch_update_dir<3, false, 223>(c, parity, dir, xs_begin, xs_count, side);
+        else rc = launch_update_dir<3, false, 0>(c, parity, dir, xs_begin, xs_count, side);
     } else {
-        if (gid) launch_update_dir<2, true, 0>(c, parity, dir, xs_begin, xs_count, side);
-        else if (lux3) launch_update_dir<2, false, 223>(c, parity, dir, xs_begin, xs_count, side);
-        else launch_update_dir<2, false, 0>(c, parity, dir, xs_begin, xs_count, side);
+        if (gid) rc = launch_update_dir<2, true, 0>(c, parity, dir, xs_begin, xs_count, side);
+        else if (lux3) rc = launch_update_dir<2, false, 223>(c, parity, dir, xs_begin, xs_count, side);
+        else rc = launch_update_dir<2, false, 0>(c, parity, dir, xs_begin, xs_count, side);
     }
+    if (rc) return rc;
     return tm.finish();
 }
 

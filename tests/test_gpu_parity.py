@@ -441,3 +441,18 @@ def test_overrelaxation_leaves_the_measure_alone(fname, group):
     m_gpu, e_gpu = _binned(mine, 25)
     assert abs(m_ref - m_gpu) < 4.0 * np.hypot(e_ref, e_gpu), (m_ref, e_ref, m_gpu, e_gpu)
     assert e_gpu < 1e-3
+
+
+def test_partial_passes_must_tile_the_slab():
+    """All random streams of a launch are read from the same state slot, and a pass flips it: a range
+    whose slices have been through different numbers of passes is refused, not silently mis-seeded."""
+    import qcdgpu_amd as q
+    with q.Context(group=3, L=(8, 4, 4, 4), beta=6.0, x0=0, nx_local=8, halo=1) as c:
+        c.init_lattice()
+        c.update_range(1, 0, 0, 2)          # slices 0, 1 of the pass ...
+        with pytest.raises(q.QcdError, match="pass"):
+            c.update_range(1, 0, 0, 8)      # ... so the whole slab is no longer in step
+        c.update_range(1, 0, 2, 6)          # the rest of the pass: in step again
+        c.update_range(1, 1, 6, 4)          # wraps around: slices 6, 7, 0, 1
+        c.update_range(1, 1, 2, 4)
+        c.update(0, 0)
