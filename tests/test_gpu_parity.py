@@ -111,6 +111,8 @@ def test_gid_runs_match_reference_vectors(case):
     (3, (6, 4, 4, 6), 1.5, 2, 4, 99),      # low beta: many rejected trials, batch refills
     (2, (8, 8, 8, 8), 2.5, 10, 3, 54),
     (2, (6, 8, 4, 10), 1.2, 2, 2, 7),
+    (3, (4, 4, 4, 6), 1.0, 12, 3, 5),      # more than 48 numbers per link for many links: the redo pass
+    (2, (4, 4, 6, 4), 0.5, 14, 1, 8),      # the same for SU(2)
 ])
 def test_ranlux_runs_match_checker(group, L, beta, nhit, lux, seed):
     """Production RNG mode: one RANLUX stream per thread.  Same streams on both sides, so the
@@ -126,7 +128,8 @@ def test_ranlux_runs_match_checker(group, L, beta, nhit, lux, seed):
             assert _rel(c.action(), lat.action()) < 1e-10   # S = beta(1 - Plq/N): cancellation
         assert np.allclose(c.polyakov(), lat.polyakov(), rtol=1e-10, atol=1e-13)
         got, want = c.download(), lat.export_table()
-        assert np.max(np.abs(got - want)) < 1e-10
+        # rounding differences between the two libms grow from sweep to sweep, fastest at small beta
+        assert np.max(np.abs(got - want)) < (1e-10 if beta > 1.0 else 1e-9)
     lat.close()
 
 
