@@ -459,3 +459,28 @@ def test_partial_passes_must_tile_the_slab():
         c.update_range(1, 1, 6, 4)          # wraps around: slices 6, 7, 0, 1
         c.update_range(1, 1, 2, 4)
         c.update(0, 0)
+
+
+@pytest.mark.parametrize("beta,nhit", [(6.0, 10), (1.0, 12)])
+def test_generator_state_round_trip_mid_sweep(beta, nhit):
+    """Links and generator state saved after an ODD number of passes (the states then sit in the
+    second of their two slots; at beta = 1 many went through the redo pass) and loaded into a fresh
+    context: both contexts continue to the same links, bit for bit."""
+    import qcdgpu_amd as q
+    L = (4, 6, 4, 4)
+    with q.Context(group=3, L=L, beta=beta, nhit=nhit, rand_series=21) as a, \
+            q.Context(group=3, L=L, beta=beta, nhit=nhit, rand_series=99) as b:
+        a.init_lattice()
+        a.sweep(1)
+        a.update(1, 0)
+        table, state = a.download(), a.rng_state()
+        b.upload(table)
+        b.set_rng_state(state)
+        for c in (a, b):
+            for d in (1, 2, 3):
+                c.update(1, d)
+            for d in range(4):
+                c.update(0, d)
+            c.sweep(1)
+        assert a.rng_draws() == b.rng_draws()
+        assert np.array_equal(a.download(), b.download())
