@@ -941,6 +941,7 @@ __global__ __launch_bounds__(BLOCK) void k_update_redo(const UpdArgs a)
     __shared__ float rbuf[24 * 2 * BLOCK];
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.redo_count_next = 0u;
     const unsigned count = *a.redo_count;
+    if (count == 0u) return;   // the usual case (always, at large beta): nothing else to do in this launch
     unsigned long long used = 0;
     for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
         const int w = a.redo_list[i];

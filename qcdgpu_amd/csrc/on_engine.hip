@@ -165,8 +165,7 @@ int launch_measure(qcd_on_ctx* c, const int step[4])
     hipLaunchKernelGGL((k_on_measure<F, ON_MEAS_BLOCK>), dim3(c->npartial), dim3(ON_MEAS_BLOCK), 0, c->stream,
                        (const F*)c->phi, c->g, params_of<F>(c), st, c->partial);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_on_reduce<ON_MEAS_BLOCK>), dim3(1), dim3(ON_MEAS_BLOCK), 0, c->stream, c->partial, c->npartial,
-                       c->result_dev);
+    hipLaunchKernelGGL((k_on_reduce<1024>), dim3(5), dim3(1024), 0, c->stream, c->partial, c->npartial, c->result_dev);
     HIP_TRY(hipGetLastError());
     return QCD_OK;
 }
