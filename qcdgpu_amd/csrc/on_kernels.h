@@ -76,7 +76,7 @@ __device__ __forceinline__ double on_exp(double x) { return exp(x); }
 // The fp64 logarithms, the square root and the two fp64 quotients of the action come from a Math
 // policy (fastmath.h): the update pass uses the table logarithm and the hardware-seeded reciprocal
 // and square root (errors of 1e-16 in an action of order one, the size of the difference between
-// any two libms), the measurements use the device libm.
+// any two libms); the measurement kernel uses the same.
 
 // o1cl.cl:41-45
 template <typename F, class Math>
@@ -396,6 +396,9 @@ __global__ __launch_bounds__(BLOCK) void k_on_measure(const F* __restrict__ phi,
                                                       const int4 step, double* __restrict__ partial)
 {
     __shared__ double red[5][BLOCK / 64];
+    __shared__ double2 logtab[LOG_TABLE_ENTRIES];
+    MathFast::fill<BLOCK>(logtab);
+    __syncthreads();
     const int w = blockIdx.x * BLOCK + threadIdx.x;
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (w < 2 * g.vh) {
@@ -408,7 +411,9 @@ __global__ __launch_bounds__(BLOCK) void k_on_measure(const F* __restrict__ phi,
         on_forward(g, s, h, nb);
         const F Ux = own[h];
         F PhiN[4];
-        const MathLib lm;
+        MathFast lm;   // as in the update pass (a call at 64^4: 630 -> 380 us); the reference's CPU re-measurement
+                       // is reproduced to 1e-12 either way
+        lm.tab = logtab;
 #pragma unroll
         for (int k = 0; k < 4; k++) PhiN[k] = on_phi_of(other[nb[k]], p, lm);
         v[0] = (double)on_action(Ux, PhiN, p, lm);
