@@ -131,6 +131,17 @@ int qcd_measure_polyakov(qcd_ctx *ctx, double out[4]);
 int qcd_measure_plaquette_sums(qcd_ctx *ctx, double sums[2]);
 int qcd_measure_polyakov_sums(qcd_ctx *ctx, double sums[4]);
 
+/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The plaquette sums of
+ * qcd_measure_plaquette_sums computed by the same kernels, with the per-workgroup partial sums in a
+ * static array of the library's code object (1 MiB per device, held until the process ends)
+ * instead of in allocated memory.  The call allocates nothing, does not synchronise and copies
+ * nothing to the host: sums_dev (device-accessible memory of the caller, two doubles) receives
+ * (sum_spat, sum_temp) once the context's stream has run the two kernels.  Limit: at most
+ * 65536 * 256 = 2^24 owned sites per context (QCD_ERR_UNSUPPORTED beyond).  All calls on one
+ * device share that device's array: calls that overlap in time on one device race. */
+int qcd_measure_plaquette_sums_static(qcd_ctx *ctx, double *sums_dev);
+
 /* kernel_run(sun_measurement_plq_id) built with FMUNU or F0MU + its reduce kernel (suncl.cpp:5478-5483;
  * kernel lattice_measurement_plq, sun_measurements_cl.cl:712-1175; CPU twin su3cpu.cpp:1212-1381):
  * F_re = Im Tr(P lambda_a)/2, F_im = -Re Tr(P lambda_a)/2 of the plaquette matrix P, per plane.

@@ -54,7 +54,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
-           "qcd_on_download"]
+           "qcd_on_download", "qcd_measure_plaquette_sums_static"]
 
 
 def _load():
@@ -86,6 +86,7 @@ def _load():
     for n in ("qcd_measure_plaquette", "qcd_measure_action", "qcd_measure_polyakov",
               "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums"):
         getattr(lib, n).argtypes = [P, pd]
+    lib.qcd_measure_plaquette_sums_static.argtypes = [P, P]
     lib.qcd_upload.argtypes = [P, P, C.c_size_t, I]
     lib.qcd_download.argtypes = [P, P, C.c_size_t, I]
     lib.qcd_halo_bytes.argtypes = [P]
@@ -210,6 +211,11 @@ class Context:
 
     def plaquette_sums(self):
         return self._measure(lib.qcd_measure_plaquette_sums, 2)
+
+    def plaquette_sums_static(self, dev_ptr):
+        """(sum_spat, sum_temp) into two doubles of device memory at dev_ptr, asynchronously, without
+        any allocation (the entry point for callers that cannot allocate)."""
+        _check(lib.qcd_measure_plaquette_sums_static(self.h, C.c_void_p(dev_ptr)))
 
     def polyakov_sums(self):
         return self._measure(lib.qcd_measure_polyakov_sums, 4)

@@ -59,6 +59,27 @@ constexpr size_t DRAWS_BYTES = (size_t)DRAW_SLOTS * DRAW_SLOT_STRIDE * sizeof(un
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Workspace of qcd_measure_plaquette_sums_static, the one entry point that allocates nothing: the
+// per-workgroup partial sums of the plaquette kernel live in this array of the code object instead
+// of in memory the context allocated.  Every device the library runs on holds its own copy until
+// the process ends (1 MiB).  The name is a host-side stand-in, not a device address: host code uses
+// the per-device address that hipGetSymbolAddress returned (g_scratch_ptr), never the name.
+constexpr int STATIC_PARTIALS_MAX = 65536;   // workgroups of MEAS_BLOCK sites: lattices up to 2^24 sites per context
+static __device__ __align__(256) double2 scratch[STATIC_PARTIALS_MAX];
+constexpr int STATIC_MAX_DEVICES = 64;
+double2* g_scratch_ptr[STATIC_MAX_DEVICES];   // device address of `scratch` on each device, 0 = not asked yet
+
+// address of this device's copy of `scratch`; the device must be current.  Called from qcd_create,
+// so that the entry point itself finds the address ready.
+int static_scratch_setup(int device)
+{
+    if (device < 0 || device >= STATIC_MAX_DEVICES || g_scratch_ptr[device]) return QCD_OK;
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    g_scratch_ptr[device] = (double2*)p;
+    return QCD_OK;
+}
+
 }  // namespace
 
 // error text of the other translation units of the library (qcd_last_error returns it)
@@ -470,6 +491,10 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (p->device < 0 || p->device >= ndev) return fail(QCD_ERR_INVALID, "device %d of %d", p->device, ndev);
     HIP_TRY(hipSetDevice(p->device));
+    {
+        const int rc_scratch = static_scratch_setup(p->device);
+        if (rc_scratch) return rc_scratch;
+    }
 
     qcd_ctx* c = new qcd_ctx();
     memset(c, 0, sizeof(*c));
@@ -802,6 +827,32 @@ int qcd_measure_plaquette_sums(qcd_ctx* c, double sums[2])
     if ((rc = tm.finish())) return rc;
     if ((rc = reduce_partials(c, c->npartial, 1, sums))) return rc;
     c->sites_fresh = c->site_vals != nullptr;
+    return QCD_OK;
+}
+
+// The plaquette sums without any allocation, synchronisation or host copy: the kernels of
+// qcd_measure_plaquette_sums with their partial sums in the code object's own `scratch` array and
+// the two result words stored to memory of the caller (device-accessible).  Asynchronous on the
+// context's stream.  Every call on a device shares that device's array: the plaquette kernel
+// writes all the partials the reduce kernel reads, so nothing has to be cleared between calls,
+// but calls that overlap on one device (two streams, two host threads) race.
+int qcd_measure_plaquette_sums_static(qcd_ctx* c, double* sums_dev)
+{
+    int rc = check_ctx(c, true, true, true);
+    if (rc) return rc;
+    if (!sums_dev) return fail(QCD_ERR_INVALID, "null output");
+    if (c->npartial > STATIC_PARTIALS_MAX)
+        return fail(QCD_ERR_UNSUPPORTED, "%d workgroups of partial sums exceed the static workspace of %d (at most %ld owned sites)",
+                    c->npartial, STATIC_PARTIALS_MAX, (long)STATIC_PARTIALS_MAX * MEAS_BLOCK);
+    double2* ws = (c->p.device < STATIC_MAX_DEVICES) ? g_scratch_ptr[c->p.device] : nullptr;
+    if (!ws) return fail(QCD_ERR_STATE, "no static workspace on device %d", c->p.device);
+    const dim3 grid(c->npartial), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, ws, (double2*)nullptr);
+    else hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, ws, (double2*)nullptr);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_reduce<MEAS_BLOCK>), dim3(1), dim3(MEAS_BLOCK), 0, c->stream, ws, c->npartial, sums_dev);
+    HIP_TRY(hipGetLastError());
+    c->timing.measure_launches++;
     return QCD_OK;
 }
 
