@@ -388,3 +388,35 @@ def test_64x4_lattice_one_context_equals_two_slabs():
             e.ctx.close()
     assert np.allclose(one_p, two_p, rtol=1e-13)
     assert np.allclose(one_l, two_l, rtol=1e-10, atol=1e-8)
+
+
+def test_32x4_lattice_one_context_equals_eight_slabs():
+    """BASELINE configurations 3 and 4 at their stated size: SU(3) 32^4 in one context, and the same
+    lattice cut the way an 8-GPU run cuts it, N1 = {4,4,4,4,4,4,4,4} (all parts on the one device
+    of the box).  Nx = 4 per part: the split pass updates one slice next to either face first and
+    leaves an interior of two.  Same plaquette sums (1e-13), Polyakov sums and counts of random
+    numbers after two sweeps, and both equal the CPU checker's fixture for this lattice."""
+    import qcdgpu_amd as q
+    from qcdgpu_amd import biglattice as bl
+    fx = ol.golden("persite_su3_32x32x32x32_b6.json")
+    L = (32, 32, 32, 32)
+    with q.Context(group=3, L=L, beta=6.0, nhit=10, rand_series=54) as c:
+        c.init_lattice()
+        c.sweep(2)
+        one_p, one_l, one_d = c.plaquette_sums(), c.polyakov_sums(), c.rng_draws()
+        assert np.max(np.abs(c.plaquette() - fx["sweeps"][1]["plaquette"]) / np.abs(fx["sweeps"][1]["plaquette"])) < 1e-12
+    big = bl.make_gpu_slabs(3, L, 6.0, [4] * 8, nhit=10, rand_series=54)
+    try:
+        assert big.boundary_depth() == 1
+        big.sweep(2)
+        many_p = np.sum([e.plaquette_sums() for e in big.engines], axis=0)
+        many_l = np.sum([e.polyakov_sums() for e in big.engines], axis=0)
+        many_d = sum(e.ctx.rng_draws() for e in big.engines)
+        plq = big.plaquette()
+    finally:
+        for e in big.engines:
+            e.ctx.close()
+    assert many_d == one_d == fx["sweeps"][1]["rng_draws"]
+    assert np.allclose(one_p, many_p, rtol=1e-13)
+    assert np.allclose(one_l, many_l, rtol=1e-10, atol=1e-8)
+    assert np.max(np.abs(plq - fx["sweeps"][1]["plaquette"]) / np.abs(fx["sweeps"][1]["plaquette"])) < 1e-12

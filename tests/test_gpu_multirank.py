@@ -1,0 +1,79 @@
+"""The N > 1 path on the GPU: two (and four) ranks as child processes on the one device of the
+box, through make_rank_slab -> GpuSlabEngine + TorchDistComm -- the code an N-GPU bench run takes,
+with gloo staging in place of RCCL -- against the uncut lattice of the CPU checker: plaquette and
+Polyakov loop per sweep, the count of random numbers drawn, and the concatenated link table."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, cfg, tmp_path):
+    cfg = dict(cfg, dir=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "gpu_slab_worker.py"), json.dumps(cfg)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    with open(tmp_path / "rows.json") as f:
+        doc = json.load(f)
+    links = np.concatenate([np.load(tmp_path / ("links_%d.npy" % k)) for k in range(world)], axis=1)
+    return doc, links
+
+
+@pytest.mark.parametrize("world,cfg", [
+    (2, dict(group=3, L=[16, 4, 4, 6], beta=5.8, nhit=4, seed=29, ints=1, sweeps=2)),
+    (2, dict(group=3, L=[16, 4, 4, 6], beta=1.0, nhit=12, seed=29, ints=1, sweeps=2)),   # redo lists of both lanes busy
+    (4, dict(group=2, L=[16, 4, 6, 4], beta=2.3, nhit=5, seed=7, ints=1, sweeps=2)),     # Nx = 4 per rank
+    (2, dict(group=3, L=[8, 4, 4, 4], beta=5.9, nhit=4, seed=3, ints=0, sweeps=1)),      # hot start: halos by exchange
+])
+def test_gpu_ranks_reproduce_uncut_lattice(world, cfg, tmp_path):
+    doc, links = _run(world, cfg, tmp_path)
+    mode = ol.RNG_PERSITE
+    lat = ol.Lattice(cfg["group"], cfg["L"], cfg["beta"], nhit=cfg["nhit"], ints=cfg["ints"], rng_mode=mode,
+                     seed=cfg["seed"])
+    for row in doc["rows"]:
+        lat.sweep(1)
+        want = np.concatenate([lat.plaquette(), lat.polyakov()])
+        got = np.array(row)
+        assert np.max(np.abs(got[:3] - want[:3]) / np.abs(want[:3])) < 1e-12
+        assert np.allclose(got[3:], want[3:], rtol=1e-10, atol=1e-13)
+    assert doc["draws"] == ol.rng_draws(lat)
+    assert np.max(np.abs(links - lat.export_table())) < 1e-11
+    assert doc["split"] and doc["boundary_depth"] == (1 if cfg["L"][0] // world >= 4 else 0)
+    lat.close()
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the process starts two ranks as children and
+    prints rank 0's JSON line (both ranks on device 0, gloo staging: the one-GPU rehearsal switches)."""
+    env = dict(os.environ, QCDGPU_BENCH_SHARE_DEVICE="1", QCDGPU_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--brackets", "2", "--L", "16", "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    doc = json.loads(line)
+    assert doc["n_gpus"] == 2 and doc["config"]["lattice"] == [32, 16, 16, 16]
+    assert doc["value"] > 0 and doc["roofline"]["launches"] >= 16
+    # 5 sweeps of 32 x 16^3 from a cold start at beta = 6: the plaquette has left 3 and is still above its equilibrium value
+    assert 1.7 < doc["mean_plaquette"]["Plq_total"] < 2.2

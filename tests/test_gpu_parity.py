@@ -484,3 +484,42 @@ def test_generator_state_round_trip_mid_sweep(beta, nhit):
             c.sweep(1)
         assert a.rng_draws() == b.rng_draws()
         assert np.array_equal(a.download(), b.download())
+
+
+def test_config2_su3_16_heatbath_and_overrelaxation_vs_cpu():
+    """BASELINE configuration 2 at its stated size: SU(3) 16^4 fp64, heat-bath AND overrelaxation
+    sweeps alternating, plaquette against the CPU path to 1e-12 after every sweep (the
+    overrelaxation half has no counterpart in the reference: checked against the checker's
+    restatement and by the action staying put)."""
+    L = (16, 16, 16, 16)
+    lat = ol.Lattice(3, L, 6.0, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE)
+    with _ctx(group=3, L=L, beta=6.0, nhit=10) as c:
+        c.init_lattice()
+        for sweep in range(2):
+            c.sweep(1)
+            lat.sweep(1)
+            assert _rel(c.plaquette(), lat.plaquette()) < REL, sweep
+            before = c.plaquette()[2]
+            c.overrelax_sweep(1)
+            lat.overrelax_sweep(1)
+            assert abs(c.plaquette()[2] - before) < 1e-13, sweep
+            assert _rel(c.plaquette(), lat.plaquette()) < REL, sweep
+            assert c.rng_draws() == ol.rng_draws(lat)
+        assert np.allclose(c.polyakov(), lat.polyakov(), rtol=1e-10, atol=1e-13)
+    lat.close()
+
+
+def test_config3_su3_32_against_checker_fixture():
+    """BASELINE configuration 3 at its stated size: SU(3) 32^4, beta 6, cold start, two heat-bath
+    sweeps against the CPU checker's per-thread-stream run of the same lattice (committed fixture,
+    oracle/make_golden_persite32.py): plaquette to 1e-12, equal counts of random numbers drawn
+    (the same accept/reject history at every one of 8.4 million link updates), Polyakov loop."""
+    fx = ol.golden("persite_su3_32x32x32x32_b6.json")
+    L = (32, 32, 32, 32)
+    with _ctx(group=3, L=L, beta=6.0, nhit=10, rand_series=54) as c:
+        c.init_lattice()
+        for row in fx["sweeps"]:
+            c.sweep(1)
+            assert c.rng_draws() == row["rng_draws"], row["sweep"]
+            assert _rel(c.plaquette(), row["plaquette"]) < REL, row["sweep"]
+            assert np.allclose(c.polyakov(), row["polyakov"], rtol=1e-9, atol=1e-13), row["sweep"]
