@@ -50,7 +50,6 @@ int fail(int code, const char* fmt, ...)
 #define QCD_UPD_BLOCK 64
 #endif
 constexpr int UPD_BLOCK = QCD_UPD_BLOCK;
-constexpr int REDO_BLOCK = 64, REDO_GRID = 128;
 #ifndef QCD_MEAS_BLOCK
 #define QCD_MEAS_BLOCK 256
 #endif
@@ -98,6 +97,8 @@ struct qcd_ctx {
     Geom g;
     int ncomp;
     int upd_grid;             // workgroups per update launch (0: one per block of sites)
+    int gh_grid;              // workgroups (one per CU) of the gather / heat-bath pair kernel (0: not available)
+    int gh_mode;              // 0 never, 1 when the launch has at least 8 * gh_grid blocks, 2 whenever possible
     hipStream_t own_stream, stream;
     double2* U;
     size_t U_elems;
@@ -116,16 +117,11 @@ struct qcd_ctx {
     double* result_host_dev;  // the same memory as the device addresses it
     unsigned long long* draws_dev;   // DRAW_SLOTS partial counts, DRAW_SLOT_STRIDE elements apart
     unsigned long long* draws_host;  // pinned, same shape
-    int* redo_list;           // update pass: sites left to the general random stream
-    unsigned* redo_count;     // two counters, used by alternate passes (a second pair for the side lane)
-    unsigned pass_no;
     // side lane of qcd_update_split: the rest of a pass runs on its own stream, next to the
     // boundary part on the context's stream
     hipStream_t side_stream;
     hipEvent_t fork_ev, join_ev;
     bool side_pending;        // the context's stream has not yet waited for the side lane's last launch
-    int* redo_list_side;
-    unsigned pass_no_side;
     bool initialized;
     bool profiling;
     hipEvent_t ev0, ev1;
@@ -206,35 +202,32 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
-    // each lane has its own list and counter pair: its launches are ordered, the lanes are not
-    unsigned& pass_no = side ? c->pass_no_side : c->pass_no;
-    unsigned* counts = c->redo_count + (side ? 2 : 0);
-    a.redo_list = side ? c->redo_list_side : c->redo_list;
-    a.redo_count = counts + (pass_no & 1u);
-    a.redo_count_next = counts + ((pass_no + 1u) & 1u);
-    pass_no++;
+    bool paired = false;   // launched as the gather / heat-bath pair kernel
+    if constexpr (GROUP == 3 && !GID && UPD_BLOCK == 64) {
+        // it has no code for partly filled blocks
+        const bool full = ((long)g.unx * g.region_h) % UPD_BLOCK == 0 && g.tz == 0;
+        if (c->gh_grid > 0 && full && (c->gh_mode == 2 || (c->gh_mode == 1 && nblocks >= 2 * GH_SIDE * c->gh_grid))) {
+            paired = true;
+            const dim3 ggrid(c->gh_grid), gblock(512);
+#define QCD_LAUNCH_GH(D) hipLaunchKernelGGL((k_update_gh<D, NSKIP, GH_TEAMS>), ggrid, gblock, 0, stream, a)
+            switch (dir) {
+                case 0: QCD_LAUNCH_GH(0); break;
+                case 1: QCD_LAUNCH_GH(1); break;
+                case 2: QCD_LAUNCH_GH(2); break;
+                default: QCD_LAUNCH_GH(3); break;
+            }
+#undef QCD_LAUNCH_GH
+        }
+    }
 #define QCD_LAUNCH_UPDATE(D) \
     hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, stream, a)
-    switch (dir) {
+    if (!paired) switch (dir) {
         case 0: QCD_LAUNCH_UPDATE(0); break;
         case 1: QCD_LAUNCH_UPDATE(1); break;
         case 2: QCD_LAUNCH_UPDATE(2); break;
         default: QCD_LAUNCH_UPDATE(3); break;
     }
 #undef QCD_LAUNCH_UPDATE
-    if (!GID) {
-        // the few sites (none at large beta) whose random window ran dry; also re-arms the list
-        const dim3 rgrid(REDO_GRID), rblock(REDO_BLOCK);
-#define QCD_LAUNCH_REDO(D) \
-    hipLaunchKernelGGL((k_update_redo<GROUP, D, REDO_BLOCK, UPD_BLOCK>), rgrid, rblock, 0, stream, a)
-        switch (dir) {
-            case 0: QCD_LAUNCH_REDO(0); break;
-            case 1: QCD_LAUNCH_REDO(1); break;
-            case 2: QCD_LAUNCH_REDO(2); break;
-            default: QCD_LAUNCH_REDO(3); break;
-        }
-#undef QCD_LAUNCH_REDO
-    }
     return QCD_OK;
 }
 
@@ -559,6 +552,14 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
             c->upd_grid = resident / regions_of(g) * regions_of(g);
         }
     }
+    c->gh_grid = 0;
+    c->gh_mode = 1;
+    if (p->group == 3) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess)
+            c->gh_grid = prop.multiProcessorCount / regions_of(g) * regions_of(g);
+    }
+    if (const char* ov = getenv("QCDGPU_AMD_GH")) c->gh_mode = atoi(ov);              // diagnostic override: 0, 1 or 2
     if (const char* ov = getenv("QCDGPU_AMD_GRID")) {  // diagnostic override: workgroups per update launch
         const int v = atoi(ov);                        // (0: one workgroup per block of sites)
         c->upd_grid = v > 0 ? (v + regions_of(g) - 1) / regions_of(g) * regions_of(g) : 0;
@@ -593,11 +594,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(result)");
     if (rc == QCD_OK) tryhip(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0), "hipHostGetDevicePointer(result)");
     tryhip(hipMalloc(&c->draws_dev, DRAWS_BYTES), "hipMalloc(draws)");
-    tryhip(hipMalloc(&c->redo_list, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list)");
-    tryhip(hipMalloc(&c->redo_count, 4 * sizeof(unsigned)), "hipMalloc(redo count)");
-    if (rc == QCD_OK) tryhip(hipMemset(c->redo_count, 0, 4 * sizeof(unsigned)), "hipMemset(redo count)");
     if (g.halo) {   // slabs only: the side lane of qcd_update_split
-        tryhip(hipMalloc(&c->redo_list_side, (size_t)g.vh_int * sizeof(int)), "hipMalloc(redo list, side lane)");
         tryhip(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "hipStreamCreate(side lane)");
         tryhip(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming), "hipEventCreate");
         tryhip(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming), "hipEventCreate");
@@ -626,9 +623,6 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipFree(c->loops);
     (void)hipFree(c->site_vals);
     (void)hipFree(c->draws_dev);
-    (void)hipFree(c->redo_list);
-    (void)hipFree(c->redo_count);
-    (void)hipFree(c->redo_list_side);
     if (c->side_stream) {
         (void)hipStreamSynchronize(c->side_stream);
         (void)hipStreamDestroy(c->side_stream);
@@ -1466,6 +1460,19 @@ int qcd_host_rlx_pack_check(unsigned seed, int n, unsigned* errors)
 }
 
 }  // extern "C"
+
+#ifdef QCD_GH_STATS
+// diagnostic build only: sleeps the two sides of the gather / heat-bath pairs spent waiting for each other
+extern "C" int qcd_debug_gh_spins(unsigned long long out[2], int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qcd::g_gh_spins), 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[2] = {0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(qcd::g_gh_spins), z, 16);
+    }
+    return (int)e;
+}
+#endif
 
 #ifdef QCD_TRACE
 // diagnostic build only: copies the per-wave phase stamps of the last k_update launch

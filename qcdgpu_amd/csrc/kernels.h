@@ -22,6 +22,8 @@ namespace qcd {
 
 // delivered RANLUX batches held in LDS per thread by the update kernel
 constexpr int RLX_WINDOW = 2;
+// rows of a thread's LDS column: the window and four more, through which values beyond the window are handed out
+constexpr int RLX_ROWS = 24 * RLX_WINDOW + 4;
 
 // ---------------------------------------------------------------------------------------------
 // random sources of the heat-bath
@@ -86,12 +88,19 @@ struct RlxHome {
     }
 };
 
-// The stream as the update kernel normally uses it: two delivered batches (48 values) are
-// written to LDS column `tid` when the stream is opened, and the generator is dead after that --
-// no registers held, no branch into generator code while the heat-bath runs.  An SU(3) link
-// update needs 18 values plus 4 per rejected trial, so the window covers seven rejections.  A
-// thread that runs dry reports it (close() < 0) and the kernel repeats that one link with the
-// general stream below, starting from the same persistent state.
+// The stream as the update kernel uses it: two delivered batches (48 values) are written to LDS
+// column `tid` when the stream is opened, and the generator's registers are dead after that -- no
+// registers held, no generator code in the way while the heat-bath runs.  An SU(3) link update needs
+// 18 values plus 4 per rejected trial, so the window covers seven rejections; at beta = 6 one lane
+// in 400 touches the second batch and practically none the end of it.
+// A lane that does use up the window goes on with the same generator in another form: its state
+// (in front of the third batch, rebuilt from the one the opening left in memory) lies in the first
+// 24 rows of its LDS column -- the window's values are all spent by then -- and is stepped in a
+// run-time loop with run-time indices; every further batch is delivered to rows 24..47 and the
+// skip behind it is done at once, so the column always holds the state in front of the next
+// batch.  Slow (about a link update's worth of instructions per batch), small, without a call
+// and without registers of its own besides a rotation count and the carry; it runs for the few
+// lanes that need it, at small beta for many.
 template <int BLOCK, int NSKIP>
 struct RlxFast {
     __device__ __forceinline__ void skip(RlxRegs& r) const
@@ -99,10 +108,11 @@ struct RlxFast {
         if (NSKIP > 0) rlx_skip_static<(NSKIP > 0 ? NSKIP : 24)>(r);
         else rlx_skip(r, h.q, h.rem);
     }
-    const float* buf;
+    float* buf;
     RlxHome h;
     int pos, cur;
-    bool dry;
+    int rot;          // slow form: physical row of logical word k is (k + rot) mod 24
+    unsigned carry;   // slow form: the generator's carry
 
     // The three steps of opening the stream, separate so that the kernel can place the state's
     // loads under other work:
@@ -111,9 +121,10 @@ struct RlxFast {
     {
         h.bind(view, stream);
         buf = lds_column;
-        dry = false;
         pos = 0;
         cur = view.cur;
+        rot = 0;
+        carry = 0u;
     }
     // fetch: request the generator state in front of the stream's next batch
     __device__ __forceinline__ void fetch(RlxRegs& r) const
@@ -126,11 +137,10 @@ struct RlxFast {
     __device__ __forceinline__ void generate(RlxRegs& r)
     {
 #ifndef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
-        float* lds_column = const_cast<float*>(buf);
-        rlx_batch(r, lds_column, BLOCK);
+        rlx_batch(r, buf, BLOCK);
         skip(r);
         h.store_state(r, cur ^ 1);   // in front of the second batch: the usual next state
-        rlx_batch(r, lds_column + 24 * BLOCK, BLOCK);
+        rlx_batch(r, buf + 24 * BLOCK, BLOCK);
 #endif
     }
     __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
@@ -140,30 +150,144 @@ struct RlxFast {
         fetch(r);
         generate(r);
     }
-    __device__ __forceinline__ float next()
+    // ---- the slow form
+    __device__ __forceinline__ unsigned* words() const { return reinterpret_cast<unsigned*>(buf); }
+    // one subtract-with-borrow step on logical words 23 and 9, then a rotation by one word
+    // (rlx_step_rotate on the LDS column); returns the new word
+    __device__ __forceinline__ unsigned slow_step()
     {
-        if (pos >= 24 * RLX_WINDOW) {
-            dry = true;
-            return 0.5f;
+        int ip = rot + 23, jp = rot + 9;
+        ip = ip >= 24 ? ip - 24 : ip;
+        jp = jp >= 24 ? jp - 24 : jp;
+        unsigned* w = words();
+        unsigned co;
+        const unsigned t = __builtin_subc(w[jp * BLOCK], w[ip * BLOCK], carry, &co);
+        carry = co;
+        const unsigned v = t & 0xFFFFFFu;
+        w[ip * BLOCK] = v;
+        rot = rot == 0 ? 23 : rot - 1;
+        return v;
+    }
+    __device__ __forceinline__ void slow_skip(int n)
+    {
+#pragma unroll 1
+        for (int k = 0; k < n; k++) (void)slow_step();
+    }
+    // the state in front of the second batch (memory, slot cur ^ 1) into the column's first 24 rows
+    __device__ __forceinline__ void slow_load()
+    {
+        typedef unsigned quad_t __attribute__((ext_vector_type(4)));
+        const quad_t* __restrict__ p = (const quad_t*)(h.s0 + (size_t)(cur ^ 1) * RLX_SLOT_WORDS * h.ns);
+        unsigned* w = words();
+        unsigned d[RLX_SLOT_WORDS];
+#pragma unroll
+        for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
+            const quad_t v = p[(size_t)q4 * h.ns];
+            d[4 * q4] = v.x; d[4 * q4 + 1] = v.y; d[4 * q4 + 2] = v.z; d[4 * q4 + 3] = v.w;
         }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            unsigned s4[4];
+            rlx_unpack4(d[3 * j], d[3 * j + 1], d[3 * j + 2], s4);
+#pragma unroll
+            for (int m = 0; m < 4; m++) w[(4 * j + m) * BLOCK] = s4[m];
+        }
+        carry = d[18];
+        rot = 0;
+    }
+    __device__ __forceinline__ void slow_store()
+    {
+        typedef unsigned quad_t __attribute__((ext_vector_type(4)));
+        quad_t* __restrict__ p = (quad_t*)(h.s0 + (size_t)(cur ^ 1) * RLX_SLOT_WORDS * h.ns);
+        const unsigned* w = words();
+        unsigned d[RLX_SLOT_WORDS];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            unsigned s4[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                int ph = 4 * j + m + rot;
+                ph = ph >= 24 ? ph - 24 : ph;
+                s4[m] = w[ph * BLOCK];
+            }
+            rlx_pack4(s4, d[3 * j], d[3 * j + 1], d[3 * j + 2]);
+        }
+        d[18] = carry;
+        d[19] = 0u;
+#pragma unroll
+        for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
+            quad_t v;
+            v.x = d[4 * q4]; v.y = d[4 * q4 + 1]; v.z = d[4 * q4 + 2]; v.w = d[4 * q4 + 3];
+            p[(size_t)q4 * h.ns] = v;
+        }
+    }
+    // deliver the next batch to rows 24..47 and skip behind it (rlx_batch + rlx_skip, run-time form;
+    // the word the tiny-value correction reads is word (32 - k) mod 24 of the frame the batch started in)
+    __device__ __forceinline__ void slow_refill()
+    {
+        const int nskip = NSKIP > 0 ? NSKIP : 24 * h.q + h.rem;
+        if (pos == 24 * RLX_WINDOW) {
+            slow_load();
+            slow_skip(24 + nskip);   // over the second batch, which the opening delivered, and the skip behind it
+        }
+        const int rot0 = rot;
+        float* out = buf + 24 * BLOCK;
+        const unsigned* w = words();
+#pragma unroll 1
+        for (int k = 0; k < 24; k++) {
+            const unsigned ui = slow_step();
+            float uni = (float)ui * RLX_TWOM24;
+            if (ui < 4096u) {
+                int ph = ((32 - k) % 24) + rot0;
+                ph = ph >= 24 ? ph - 24 : ph;
+                uni = uni + RLX_TWOM24 * ((float)w[ph * BLOCK] * RLX_TWOM24);
+                if (uni == 0.0f) uni = RLX_TWOM24 * RLX_TWOM24;
+            }
+            out[k * BLOCK] = uni;
+        }
+        slow_skip(nskip);
+    }
+    // N values (4 or 2).  Inside the window: N reads.  Beyond: one at a time, through the N rows behind
+    // the window, so that the refill's code exists once per call site.
+    template <int N>
+    __device__ __forceinline__ void draw(float r[N])
+    {
 #ifdef QCD_ABL_RNG
-        return 0.37f + 0.001f * (float)(pos++ % 24);
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = 0.37f + 0.001f * (float)(pos++ % 24);
+        return;
 #endif
-        return buf[(pos++) * BLOCK];
+        if (__builtin_expect(pos + N <= 24 * RLX_WINDOW, 1)) {
+#pragma unroll
+            for (int k = 0; k < N; k++) r[k] = buf[(pos + k) * BLOCK];
+            pos += N;
+            return;
+        }
+#pragma unroll 1
+        for (int k = 0; k < N; k++) {
+            float v;
+            if (pos < 24 * RLX_WINDOW) {
+                v = buf[pos * BLOCK];
+            } else {
+                const int m = pos % 24;
+                if (m == 0) slow_refill();
+                v = buf[(24 + m) * BLOCK];
+            }
+            buf[(24 * RLX_WINDOW + k) * BLOCK] = v;
+            pos++;
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) r[k] = buf[(24 * RLX_WINDOW + k) * BLOCK];
     }
-    __device__ __forceinline__ void draw4(float r[4])
-    {
-        r[0] = next(); r[1] = next(); r[2] = next(); r[3] = next();
-    }
-    __device__ __forceinline__ void draw2(float r[2])
-    {
-        r[0] = next(); r[1] = next();
-    }
-    // number of values used, or -1 when the window ran dry (nothing was made persistent then)
+    __device__ __forceinline__ void draw4(float r[4]) { draw<4>(r); }
+    __device__ __forceinline__ void draw2(float r[2]) { draw<2>(r); }
+    // number of values used; leaves the stream's state in front of its next batch in slot cur ^ 1
     __device__ __forceinline__ int close()
     {
-        if (dry) return -1;
-        if (pos > 24) {
+#ifndef QCD_ABL_RNG
+        if (pos > 24 * RLX_WINDOW) {
+            slow_store();   // the slow form keeps the state in front of the next batch
+        } else if (pos > 24) {
             // rare (two or more rejected trials): the second batch was touched, the stream resumes in
             // front of the third; rebuild that state from the one in front of the second, in place
             // (every stream leaves a pass with its state in slot cur ^ 1)
@@ -171,86 +295,6 @@ struct RlxFast {
             h.load_state(r, cur ^ 1);
             rlx_round(r);
             skip(r);
-            h.store_state(r, cur ^ 1);
-        }
-        return pos;
-    }
-};
-
-// The general stream: any number of values, two delivered batches in LDS used as a ring and
-// refilled on demand.  Only threads whose fast window ran dry come here (many rejected trials:
-// small beta), so this path is written for size, not speed.
-template <int BLOCK>
-struct RlxStream {
-    float* buf;
-    RlxHome h;
-    int pos, nb, cur;   // nb batches delivered so far; state in front of batch k is in slot cur^(k&1)
-                        // for k = nb-1 and k = nb-2
-
-    __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
-    {
-        h.bind(view, stream);
-        buf = lds_column;
-        pos = 0;
-        cur = view.cur;
-#ifdef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
-        nb = 1000;
-        return;
-#endif
-        RlxRegs r;
-        h.load_state(r, cur);
-        rlx_batch(r, buf, BLOCK);
-        rlx_skip(r, h.q, h.rem);
-        h.store_state(r, cur ^ 1);
-        rlx_batch(r, buf + 24 * BLOCK, BLOCK);
-        nb = 2;
-    }
-    // state in front of batch nb from the one in front of batch nb-1
-    __device__ __forceinline__ void advance(RlxRegs& r)
-    {
-        h.load_state(r, cur ^ ((nb - 1) & 1));
-        rlx_round(r);
-        rlx_skip(r, h.q, h.rem);
-        h.store_state(r, cur ^ (nb & 1));
-    }
-    // both delivered batches are used up: deliver the next one over the older
-    __device__ __noinline__ void refill()
-    {
-        RlxRegs r;
-        advance(r);
-        rlx_batch(r, buf + (nb & 1) * 24 * BLOCK, BLOCK);
-        nb++;
-    }
-    __device__ __forceinline__ float next()
-    {
-        if (pos == 24 * nb) refill();
-        const int b = pos / 24;
-        const int k = pos - 24 * b;
-        pos++;
-#ifdef QCD_ABL_RNG
-        return 0.37f + 0.001f * (float)k;
-#endif
-        return buf[((b & 1) * 24 + k) * BLOCK];
-    }
-    __device__ __forceinline__ void draw4(float r[4])
-    {
-        r[0] = next(); r[1] = next(); r[2] = next(); r[3] = next();
-    }
-    __device__ __forceinline__ void draw2(float r[2])
-    {
-        r[0] = next(); r[1] = next();
-    }
-    __device__ __forceinline__ int close()
-    {
-#ifndef QCD_ABL_RNG
-        // the stream resumes in front of the batch after the last one touched; like every stream it
-        // leaves the pass with that state in slot cur ^ 1
-        const int m = (pos - 1) / 24;
-        RlxRegs r;
-        if (m == nb - 1) advance(r);
-        const int at = cur ^ ((m + 1) & 1);   // slot the state in front of batch m + 1 is in
-        if (at == cur) {
-            h.load_state(r, cur);
             h.store_state(r, cur ^ 1);
         }
 #endif
@@ -803,16 +847,13 @@ struct UpdArgs {
     const float* gidr;
     unsigned long long* draws;
     int nblocks;   // blocks of BLOCK sites in the pass; workgroup b takes b, b + gridDim.x, ...
-    int* redo_list;        // sites whose two-batch window ran dry in this pass (block * BLOCK + thread)
-    unsigned* redo_count;  // their number; zeroed by the redo kernel of the pass before
-    unsigned* redo_count_next;
 };
 
 template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK>
 __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs args_by_value)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs the signature only
-    __shared__ float rbuf[GID ? 1 : 24 * RLX_WINDOW * BLOCK];
+    __shared__ float rbuf[GID ? 1 : RLX_ROWS * BLOCK];
     __shared__ double2 logtab[LOG_TABLE_ENTRIES];
     MathFast::fill<BLOCK>(logtab);
     __syncthreads();
@@ -901,15 +942,8 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
         } else {
             update_link<false>(Ul, A, beta_eff, ap->beta_inv, nhit, rs, fm);
             QCD_STAMP(3);
-            const int n = rs.close();
-            if (n < 0) {
-                // window ran dry (many rejected trials): the link and its stream stay as they
-                // were and the site goes on the list that k_update_redo works off after this pass
-                ap->redo_list[atomicAdd(ap->redo_count, 1u)] = wb * BLOCK + (int)threadIdx.x;
-            } else {
-                used += (unsigned long long)n;
-                store_link_buf(r_own, g, hb, Ul);
-            }
+            used += (unsigned long long)rs.close();
+            store_link_buf(r_own, g, hb, Ul);
         }
         if (GID) store_link_buf(r_own, g, hb, Ul);
         QCD_STAMP(4);
@@ -931,36 +965,240 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
 #endif
 }
 
-// Second kernel of a pass: the sites the first one put on the redo list, each updated from its
-// unchanged link and stream state with the general (refilling) stream.  Sites of one pass do not
-// read each other's links, so doing these after the others gives the same configuration.  Also
-// clears the counter the NEXT pass appends to.  Small fixed grid, grid-stride over the list.
-template <int GROUP, int DIR, int BLOCK, int FAST_BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_update_redo(const UpdArgs a)
+// ---------------------------------------------------------------------------------------------
+// where a thread's site is: byte offset of its half index, neighbour offsets, random stream
+struct SiteRef {
+    int hb;
+    NbrOff nbr;
+    int stream;
+};
+template <int BLOCK>
+__device__ __forceinline__ SiteRef site_ref(const Geom& g, int wb, int tid, int parity)
 {
-    __shared__ float rbuf[24 * 2 * BLOCK];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.redo_count_next = 0u;
-    const unsigned count = *a.redo_count;
-    if (count == 0u) return;   // the usual case (always, at large beta): nothing else to do in this launch
-    unsigned long long used = 0;
-    for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
-        const int w = a.redo_list[i];
-        Site x;
-        int t;
-        if (!site_of_workgroup<FAST_BLOCK>(a.g, w / FAST_BLOCK, w % FAST_BLOCK, a.parity, x, t)) continue;
-        const int hb = half_index(a.g, x) * 16;
-        const NbrOff nbr = neighbour_offsets(a.g, x);
-        const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(a.U, a.g, DIR, a.parity);
-        const mat<GROUP> A = staple<GROUP, DIR>(a.U, a.g, hb, nbr, a.parity);
-        mat<GROUP> Ul = load_link_buf(r_own, a.g, hb, (mat<GROUP>*)nullptr);
-        RlxStream<BLOCK> slow;
-        slow.open(a.rv, t, rbuf + threadIdx.x);
-        update_link<false>(Ul, A, a.beta_eff, a.beta_inv, a.nhit, slow, MathLib());
-        used += (unsigned long long)slow.close();
-        store_link_buf(r_own, a.g, hb, Ul);
+    Site x;
+    int t = 0;
+    (void)site_of_workgroup<BLOCK>(g, wb, tid, parity, x, t);   // every block of the launch is full
+    SiteRef r;
+    r.hb = half_index(g, x) * 16;
+    r.nbr = neighbour_offsets(g, x);
+    r.stream = t;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The SU(3) heat-bath pass as a two-stage pipeline inside the workgroup ("gather" and "heat-bath"
+// wavefronts).  One workgroup of eight wavefronts per CU, four of them gathering staple sums and
+// four running the heat-bath, in TEAMS teams: a team works on ONE block of 64 sites at a time --
+// its gather wavefronts each form the partial staple sum of their share of the six terms and
+// hand it over through LDS, its heat-bath wavefronts take turns: generate the random numbers,
+// add the partial sums, run the heat-bath, store the links -- while the gather side is already at
+// the team's next block.
+//
+// Why.  The two halves of a link update want different things: the gather waits for memory and
+// needs registers for links in flight, the heat-bath is a long chain of dependent fp64 arithmetic
+// with the staple, the link and its temporaries live.  Split over two wavefronts of one SIMD, each
+// SIMD always has one instruction stream that mostly waits and one that mostly computes (two whole
+// updates side by side are in the same phase as often as not), a block's requests come in a
+// shorter burst, and the gather side can run ahead of the heat-bath side across block boundaries.
+// Measured at 32^4, beta 6: 124.6 us per pass against 127.9 us for the kernel with one wavefront per
+// block, L2 misses 5.5 M against 5.76 M per launch.  The pass stays bound by the bytes its L2 misses
+// move (5.6 TB/s): neither side waits for the other (sleeps per block: gather 0, heat-bath 3).
+// Variants measured and dropped: teams of 2 + 2 or 4 + 4 wavefronts sharing one block (TEAMS 2, 1:
+// 127 and 134 us, no fewer misses), the requests of a direction issued pairwise per array (152 us),
+// a cap on the gather wavefronts with loads in flight (3 of 4: 130 us, 2: 137 us).
+//
+// Roles follow the SIMD a wavefront finds itself on (HW_ID): with more than 168 registers per lane
+// a SIMD holds two wavefronts, so the eight of a workgroup are two per SIMD whatever the order they
+// were placed in; the first to arrive gathers, the second runs the heat-bath, so every SIMD has one
+// stream that mostly waits for memory and one that mostly computes.
+//
+// The partial sums of a team's gather wavefronts are added in wavefront order, the terms inside a
+// partial sum in the reference's order (nu ascending, forward then backward).
+#ifdef QCD_GH_STATS   // diagnostic build: sleeps spent waiting for the other side, [0] gather side, [1] heat-bath side
+__device__ unsigned long long g_gh_spins[2];
+#define QCD_GH_SPIN(k) spins++
+#define QCD_GH_SPIN_DECL unsigned long long spins = 0
+#define QCD_GH_SPIN_FLUSH(k) do { if (lane == 0 && spins) atomicAdd(&g_gh_spins[k], spins); } while (0)
+#else
+#define QCD_GH_SPIN(k) do {} while (0)
+#define QCD_GH_SPIN_DECL do {} while (0)
+#define QCD_GH_SPIN_FLUSH(k) do {} while (0)
+#endif
+constexpr int GH_SIDE = 4;      // gather wavefronts per workgroup = heat-bath wavefronts per workgroup
+#ifndef QCD_GH_TEAMS
+#define QCD_GH_TEAMS 4          // teams per workgroup: 4 (pairs), 2 or 1; measured at 32^4: 124, 127, 134 us per pass
+#endif
+constexpr int GH_TEAMS = QCD_GH_TEAMS;
+constexpr int GH_SLOTS = 2;     // hand-over slots per team
+template <int TEAMS>
+struct GhShared {
+    static constexpr int PER = GH_SIDE / TEAMS;             // wavefronts of either kind per team
+    double2 stap[TEAMS][GH_SLOTS][PER][9][64];              // partial staple sums: 18 reals per lane
+    float rbuf[GH_SIDE][RLX_ROWS * 64];              // random numbers of the heat-bath wavefronts
+    double2 logtab[LOG_TABLE_ENTRIES];
+    unsigned full_seq[TEAMS][GH_SLOTS][PER];                // gather wavefront j has put block (full_seq - 1) into the slot
+    unsigned free_seq[TEAMS][GH_SLOTS];                     // the heat-bath side has read block (free_seq - 1) out of the slot
+    unsigned simd_count[4];
+};
+
+// the team's it-th block of sites: workgroup b works for region b % regions, the teams of the
+// workgroups of a region take consecutive blocks of it; < 0: no more blocks
+template <int TEAMS>
+__device__ __forceinline__ int gh_block(const Geom& g, const int nblocks, const int team, const int it)
+{
+    const int regions = g.nzr * g.ntr;
+    const int wgs = (int)gridDim.x / regions;
+    const int local = (it * wgs + (int)blockIdx.x / regions) * TEAMS + team;
+    if ((int)blockIdx.x >= wgs * regions || local >= nblocks / regions) return -1;
+    return local * regions + (int)blockIdx.x % regions;
+}
+
+// gather side: terms T0 .. T0 + NT - 1 of every block of the team, as one software pipeline that
+// runs across the block boundaries (the loads of a block's first term are requested before the
+// second product of the block before)
+template <int DIR, int T0, int NT, int TEAMS>
+__device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a, const Geom& g, const int team, const int j,
+                                          const int lane)
+{
+    QCD_GH_SPIN_DECL;
+    const int parity = a.parity;
+    int wb = gh_block<TEAMS>(g, a.nblocks, team, 0);
+    if (wb < 0) return;
+    SiteRef cur = site_ref<64>(g, wb, lane, parity);
+    raw_pair ab = issue_ab<DIR, T0>(a.U, g, cur.hb, cur.nbr, parity);
+    raw_link cl = issue_c<DIR, T0>(a.U, g, cur.hb, cur.nbr, parity);
+#pragma unroll 1
+    for (int it = 0;; it++) {
+        const int wbn = gh_block<TEAMS>(g, a.nblocks, team, it + 1);
+        const bool has_next = wbn >= 0;
+        SiteRef nxt = cur;
+        if (has_next) nxt = site_ref<64>(g, wbn, lane, parity);
+        su3 stap = zero<3>();
+#define QCD_GH_TERM(K)                                                                                   \
+        if (K < NT) {                                                                                    \
+            constexpr int T = T0 + (K < NT ? K : 0), TN = T0 + (K + 1 < NT ? K + 1 : 0);                 \
+            pin(ab);                                                                                     \
+            rows2 p = first_product<T>(ab);                                                              \
+            pin(p);                                                                                      \
+            if (K + 1 < NT) ab = issue_ab<DIR, TN>(a.U, g, cur.hb, cur.nbr, parity);                     \
+            else if (has_next) ab = issue_ab<DIR, T0>(a.U, g, nxt.hb, nxt.nbr, parity);                  \
+            pin(cl);                                                                                     \
+            second_product<T>(stap, p, cl);                                                              \
+            pin(stap);                                                                                   \
+            if (K + 1 < NT) cl = issue_c<DIR, TN>(a.U, g, cur.hb, cur.nbr, parity);                      \
+            else if (has_next) cl = issue_c<DIR, T0>(a.U, g, nxt.hb, nxt.nbr, parity);                   \
+        }
+        QCD_GH_TERM(0) QCD_GH_TERM(1) QCD_GH_TERM(2) QCD_GH_TERM(3) QCD_GH_TERM(4) QCD_GH_TERM(5)
+#undef QCD_GH_TERM
+        const int s = it % GH_SLOTS;
+        if (it >= GH_SLOTS) {
+            // the slot is free once the heat-bath side has read block it - GH_SLOTS out of it
+            while (__hip_atomic_load(&sh.free_seq[team][s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(it - GH_SLOTS + 1)) {
+                __builtin_amdgcn_s_sleep(4);
+                QCD_GH_SPIN(0);
+            }
+        }
+        double2* dst = &sh.stap[team][s][j][0][lane];
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst[k * 64] = make_double2(stap.e[k / 3][k % 3].re, stap.e[k / 3][k % 3].im);
+        __hip_atomic_store(&sh.full_seq[team][s][j], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!has_next) break;
+        cur = nxt;
     }
-    used = block_sum_u64<BLOCK>(used);
-    if ((threadIdx.x & 63) == 0 && used) atomicAdd(a.draws, used);
+    QCD_GH_SPIN_FLUSH(0);
+}
+
+template <int DIR, int NSKIP, int TEAMS>
+__global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    using Sh = GhShared<TEAMS>;
+    constexpr int PER = Sh::PER;
+    __shared__ Sh sh;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) sh.simd_count[threadIdx.x] = 0u;
+    if (threadIdx.x < TEAMS * GH_SLOTS * PER) (&sh.full_seq[0][0][0])[threadIdx.x] = 0u;
+    if (threadIdx.x < TEAMS * GH_SLOTS) (&sh.free_seq[0][0])[threadIdx.x] = 0u;
+    MathFast::fill<512>(sh.logtab);
+    __syncthreads();
+    const unsigned simd = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11))) & 3u;   // HW_ID bits 5:4
+    unsigned role = 0;
+    if (lane == 0) role = atomicAdd(&sh.simd_count[simd], 1u);
+    role = (unsigned)__builtin_amdgcn_readfirstlane((int)role);
+    int member = (int)simd;   // 0 .. 3 among the wavefronts of its kind
+    __syncthreads();
+    if (sh.simd_count[0] != 2u || sh.simd_count[1] != 2u || sh.simd_count[2] != 2u || sh.simd_count[3] != 2u) {
+        // not two wavefronts on every SIMD (not expected): roles by wavefront number instead
+        role = threadIdx.x >> 8;
+        member = (threadIdx.x >> 6) & 3;
+    }
+    const int team = member / PER, j = member % PER;
+    const Geom g = a.g;
+    if (role == 0) {
+        __builtin_amdgcn_s_setprio(QCD_PRIO_MEM);
+        if (PER == 1) gh_gather<DIR, 0, 6, TEAMS>(sh, a, g, team, j, lane);
+        else if (PER == 2) {
+            if (j == 0) gh_gather<DIR, 0, 3, TEAMS>(sh, a, g, team, j, lane);
+            else gh_gather<DIR, 3, 3, TEAMS>(sh, a, g, team, j, lane);
+        } else {
+            // four gather wavefronts: 2 + 2 + 1 + 1 terms
+            if (j == 0) gh_gather<DIR, 0, 2, TEAMS>(sh, a, g, team, j, lane);
+            else if (j == 1) gh_gather<DIR, 2, 2, TEAMS>(sh, a, g, team, j, lane);
+            else if (j == 2) gh_gather<DIR, 4, 1, TEAMS>(sh, a, g, team, j, lane);
+            else gh_gather<DIR, 5, 1, TEAMS>(sh, a, g, team, j, lane);
+        }
+    } else {
+        // ---- heat-bath side: this wavefront takes the team's blocks j, j + PER, ...
+        const int parity = a.parity;
+        MathFast fm;
+        fm.tab = sh.logtab;
+        unsigned long long used = 0;
+        QCD_GH_SPIN_DECL;
+        float* rcol = &sh.rbuf[member][lane];
+        __builtin_amdgcn_s_setprio(QCD_PRIO_ALU);
+#pragma unroll 1
+        for (int it = j;; it += PER) {
+            const int wb = gh_block<TEAMS>(g, a.nblocks, team, it);
+            if (wb < 0) break;
+            const SiteRef cur = site_ref<64>(g, wb, lane, parity);
+            const __amdgpu_buffer_rsrc_t r_own = link_rsrc<3>(a.U, g, DIR, parity);
+            RlxFast<64, NSKIP> rs;
+            rs.attach(a.rv, cur.stream, rcol);
+            RlxRegs r;
+            raw_link own = issue_link(r_own, g, cur.hb);
+            rs.fetch(r);
+            rs.generate(r);
+            const int s = it % GH_SLOTS;
+            su3 A = zero<3>();
+#pragma unroll
+            for (int m = 0; m < PER; m++) {
+                while (__hip_atomic_load(&sh.full_seq[team][s][m], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(it + 1)) {
+                    __builtin_amdgcn_s_sleep(4);
+                    QCD_GH_SPIN(1);
+                }
+                const double2* src = &sh.stap[team][s][m][0][lane];
+                su3 P;
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const double2 v = src[k * 64];
+                    P.e[k / 3][k % 3] = mk(v.x, v.y);
+                }
+                if (m == 0) A = P;
+                else add_to(A, P);
+            }
+            pin(A);
+            __hip_atomic_store(&sh.free_seq[team][s], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pin(own);
+            su3 Ul = as_su3(own);
+            update_link<false>(Ul, A, a.beta_eff, a.beta_inv, a.nhit, rs, fm);
+            used += (unsigned long long)rs.close();
+            store_link_buf(r_own, g, cur.hb, Ul);
+        }
+        used = block_sum_u64<64>(used);
+        if (lane == 0 && used) atomicAdd(a.draws + (size_t)((blockIdx.x * GH_SIDE + member) % DRAW_SLOTS) * DRAW_SLOT_STRIDE, used);
+        QCD_GH_SPIN_FLUSH(1);
+    }
+#endif
 }
 
 // overrelaxation pass over the links of direction DIR on the sites of one parity: same gather
