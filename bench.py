@@ -153,6 +153,12 @@ def main():
     if os.environ.get("QCDGPU_BENCH_SHARE_DEVICE"):
         local_rank = 0
     backend = os.environ.get("QCDGPU_BENCH_BACKEND", "nccl")
+    # how the halos travel at N > 1: "ring" = the C library's own pass (qcd_ring: RCCL send/receive
+    # issued below the C-ABI; torch.distributed over gloo only hands the RCCL identifier round and
+    # adds up timings and plaquette sums), "torch" = the Python driver over torch.distributed P2P
+    transport = os.environ.get("QCDGPU_BENCH_TRANSPORT", "torch" if os.environ.get("QCDGPU_BENCH_SHARE_DEVICE") else "ring")
+    if transport == "ring" and world > 1:
+        backend = "gloo"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -175,7 +181,10 @@ def main():
         plaquette = ctx.plaquette
         sync = ctx.synchronize
     else:
-        lat = bl.make_rank_slab(3, L, args.beta, rank, world, local_rank, **kw)
+        if transport == "ring":
+            lat = bl.make_rank_ring(3, L, args.beta, rank, world, local_rank, **kw)
+        else:
+            lat = bl.make_rank_slab(3, L, args.beta, rank, world, local_rank, **kw)
         ctx = lat.engines[0].ctx
         sweep = lat.sweep
         plaquette = lat.plaquette
@@ -267,7 +276,9 @@ def main():
         "data": "synthetic (cold start, beta=%.2f Markov chain, RANLUX3 per-thread streams, seed 54)" % args.beta,
         "config": {"workload": "SU(3) %dx%dx%dx%d heat-bath sweep (NHIT=10, re-unitarised), %d^4 per GPU"
                                % (L + (n,)), "lattice": list(L), "beta": args.beta, "nhit": 10,
-                   "prng": "RANLUX3", "parallelism": "x-slabs x%d" % world},
+                   "prng": "RANLUX3", "parallelism": "x-slabs x%d" % world,
+                   "halo_transport": None if world == 1 else ("RCCL send/recv issued by the C library (qcd_ring)" if transport == "ring"
+                                                              else "torch.distributed P2P, backend %s" % backend)},
         "mean_plaquette": {"Plq_spat": plq[0], "Plq_temp": plq[1], "Plq_total": plq[2],
                            "after_sweeps": sweeps_done, "parity_check": parity_check},
         "brackets": {"n": len(walls), "steps_each": args.steps, "value_median": value,

@@ -78,6 +78,9 @@ const char *qcd_last_error(void);
 int qcd_set_stream(qcd_ctx *ctx, void *hip_stream);
 int qcd_reset_stream(qcd_ctx *ctx);
 int qcd_synchronize(qcd_ctx *ctx);
+/* the stream the context's work is enqueued on at present (a hipStream_t), and the parameters it was created with */
+int qcd_get_stream(qcd_ctx *ctx, void **hip_stream);
+int qcd_get_params(const qcd_ctx *ctx, qcd_params *out);
 
 /* kernel_run(sun_init_id) (suncl.cpp:5243-5252; kernels lattice_init_cold / lattice_init_gid,
  * SU(N)/suncl/suncl.cl:163-347): cold or gid start; also resets the RANLUX streams */
@@ -205,6 +208,34 @@ int    qcd_halo_unpack(qcd_ctx *ctx, int side, int dir, int parity, const void *
  * BigLattice, suncl.cpp:4005-4061): boundary slice `pack_side` of src -> halo `recv_side` of dst,
  * same device or peer device; ordered after src's and before dst's later work. */
 int    qcd_halo_copy(qcd_ctx *src, int pack_side, qcd_ctx *dst, int recv_side, int dir, int parity);
+
+/* The BIGLAT branch of model::lattice_simulate (suncl.cpp:5026-5138): per (parity, direction) a
+ * kernel_run(sun_update_*) for every part followed by model::UpdateEdges(dir) (suncl.cpp:4005-4061).
+ * A ring holds the parts (contexts with halo = 1, in ring order) and issues such a pass in ONE call
+ * without a host synchronisation: every part updates the slice next to either face first, packs
+ * and sends them while the rest of its slab is updated beside that, receives and unpacks.
+ *   QCD_RING_COPY: all parts in this process; messages by device-to-device / peer copies
+ *                  (several parts may share a device: the reference's devParts, QCDGPU.cpp:129-134);
+ *   QCD_RING_RCCL: ncclSend / ncclRecv between ring neighbours (xGMI between the GPUs of a node);
+ *                  every part on a device of its own.  RCCL is bound at run time (dlopen).
+ * qcd_ring_create: all parts driven by this process (the reference's one-process model; RCCL
+ * communicators by ncclCommInitAll).  qcd_ring_create_rank: one part per process, `world` processes;
+ * rank 0 makes an identifier with qcd_rccl_unique_id (128 bytes) and hands it to the others by its
+ * own means (the reference has no multi-process mode: no counterpart).
+ * qcd_ring_update / _overrelax: one pass + exchange; qcd_ring_sweep: n sweeps in the reference's
+ * order; qcd_ring_fill_halos: every halo from its owner without an update (once after a hot
+ * start; copy transport).  Measurements stay per context (the *_sums entry points). */
+enum { QCD_RING_COPY = 0, QCD_RING_RCCL = 1 };
+typedef struct qcd_ring qcd_ring;
+int  qcd_ring_create(qcd_ring **out, qcd_ctx *const *parts, int nparts, int transport);
+int  qcd_rccl_unique_id(void *id, size_t bytes);
+int  qcd_ring_create_rank(qcd_ring **out, qcd_ctx *part, int rank, int world, const void *id, size_t bytes);
+void qcd_ring_destroy(qcd_ring *ring);
+int  qcd_ring_update(qcd_ring *ring, int parity, int dir);
+int  qcd_ring_overrelax(qcd_ring *ring, int parity, int dir);
+int  qcd_ring_sweep(qcd_ring *ring, int n);
+int  qcd_ring_fill_halos(qcd_ring *ring);
+int  qcd_ring_synchronize(qcd_ring *ring);
 
 /* device_select / device_initialize (clinterface.cpp:345-459): what the host needs to know */
 int qcd_device_count(int *count);

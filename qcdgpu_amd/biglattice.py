@@ -356,3 +356,65 @@ def make_rank_slab(group, L, beta, rank: int, world: int, device_index: int, dis
     if ctx_kw.get("start_mode") == capi.START_HOT:
         lat.fill_halos()
     return lat
+
+
+class RingLattice:
+    """One slab per process, passes and halo exchange issued below the C-ABI (qcd_ring over RCCL);
+    torch.distributed (any backend, gloo will do) only hands the RCCL identifier round and adds up
+    the few doubles of a measurement.  The host loop of an N-GPU run is then the C library's, as the
+    reference's is its C++ model's (SU(N)/suncl/suncl.cpp:5026-5138)."""
+
+    def __init__(self, ctx, rank: int, world: int, group: int, L: Sequence[int], beta: float, dist_group=None):
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.group, self.L, self.beta = group, tuple(L), beta
+        self.sites = int(np.prod(L))
+        self.dist, self.dist_group, self.torch = dist, dist_group, torch
+        self.on_host = dist.get_backend(dist_group) == "gloo"
+        dev = "cpu" if self.on_host else torch.device("cuda", ctx.params.device)
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(capi.Ring.unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(ident, 0, group=dist_group)
+        self.ring = capi.Ring([ctx], rank=rank, world=world, unique_id=bytes(ident.cpu().numpy().tobytes()))
+        self.engines = [self]     # the shape BigLattice has, for callers that look at engines[0].ctx
+
+    def sweep(self, n: int = 1):
+        self.ring.sweep(n)
+
+    def update(self, parity: int, direction: int):
+        self.ring.update(parity, direction)
+
+    def _global_sum(self, local: np.ndarray) -> np.ndarray:
+        dev = "cpu" if self.on_host else self.torch.device("cuda", self.ctx.params.device)
+        t = self.torch.tensor(np.asarray(local, dtype=np.float64), device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.dist_group)
+        return t.cpu().numpy()
+
+    def plaquette(self) -> np.ndarray:
+        s = self._global_sum(self.ctx.plaquette_sums())
+        v = float(self.sites)
+        return np.array([s[0] / (3 * v), s[1] / (3 * v), (s[0] + s[1]) / (6 * v)])   # SU(N)/suncpp/Measurements/Plq.h:90-92
+
+    def polyakov(self) -> np.ndarray:
+        s = self._global_sum(self.ctx.polyakov_sums())
+        n3 = float(self.L[0] * self.L[1] * self.L[2])
+        g = float(self.group)
+        return np.array([s[0] / (n3 * g), s[1] / (n3 * g), s[2] / (n3 * g * g), s[3] / (n3 * g ** 4)])
+
+    def close(self):
+        self.ring.close()
+
+
+def make_rank_ring(group, L, beta, rank: int, world: int, device_index: int, dist_group=None, **ctx_kw) -> RingLattice:
+    """This rank's slab of an L lattice cut evenly over `world` ranks, driven through qcd_ring (RCCL)."""
+    from . import capi
+    if ctx_kw.get("start_mode") == capi.START_HOT:
+        raise ValueError("hot start over the RCCL ring: not implemented (start cold or gid)")
+    parts = split_even(L[0], world)
+    ctx = capi.Context(group=group, L=L, beta=beta, device=device_index, x0=sum(parts[:rank]),
+                       nx_local=parts[rank], halo=1, **ctx_kw)
+    ctx.init_lattice()
+    return RingLattice(ctx, rank, world, group, L, beta, dist_group)

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libqcdgpu_amd.so")
-SOURCES = ["engine.hip"]
+SOURCES = ["engine.hip", "ring.hip"]
 # compiled apart, with contraction off on the device as well (see on_engine.hip)
 ON_SOURCE = "on_engine.hip"
 HEADERS = ["kernels.h", "lattice.h", "ranlux.h", "su_math.h", "host_seed.h", "fastmath.h", "on_kernels.h",
@@ -62,11 +62,12 @@ def build(force=False, verbose=False):
     libdir = os.path.dirname(LIB)
     common = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
     objs, cmds = [], []
-    for src, extra in [(SOURCES[0], ["-Xarch_host", "-ffp-contract=off"]), (ON_SOURCE, ["-ffp-contract=off"])]:
+    for src, extra in [(SOURCES[0], ["-Xarch_host", "-ffp-contract=off"]), (SOURCES[1], []),
+                       (ON_SOURCE, ["-ffp-contract=off"])]:
         obj = os.path.join(libdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         cmds.append([hipcc] + common + extra + ["-c", src, "-o", obj])
-    cmds.append([hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-o", LIB] + objs)
+    cmds.append([hipcc, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     for c in cmds:
         if verbose:
             print(" ".join(c), file=sys.stderr)

@@ -54,7 +54,9 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
-           "qcd_on_download", "qcd_measure_plaquette_sums_static"]
+           "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params",
+           "qcd_ring_create", "qcd_rccl_unique_id", "qcd_ring_create_rank", "qcd_ring_destroy", "qcd_ring_update",
+           "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize"]
 
 
 def _load():
@@ -87,6 +89,18 @@ def _load():
               "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums"):
         getattr(lib, n).argtypes = [P, pd]
     lib.qcd_measure_plaquette_sums_static.argtypes = [P, P]
+    lib.qcd_get_stream.argtypes = [P, C.POINTER(P)]
+    lib.qcd_get_params.argtypes = [P, C.POINTER(Params)]
+    lib.qcd_ring_create.argtypes = [C.POINTER(P), C.POINTER(P), I, I]
+    lib.qcd_rccl_unique_id.argtypes = [P, C.c_size_t]
+    lib.qcd_ring_create_rank.argtypes = [C.POINTER(P), P, I, I, P, C.c_size_t]
+    lib.qcd_ring_destroy.argtypes = [P]
+    lib.qcd_ring_destroy.restype = None
+    lib.qcd_ring_update.argtypes = [P, I, I]
+    lib.qcd_ring_overrelax.argtypes = [P, I, I]
+    lib.qcd_ring_sweep.argtypes = [P, I]
+    lib.qcd_ring_fill_halos.argtypes = [P]
+    lib.qcd_ring_synchronize.argtypes = [P]
     lib.qcd_upload.argtypes = [P, P, C.c_size_t, I]
     lib.qcd_download.argtypes = [P, P, C.c_size_t, I]
     lib.qcd_halo_bytes.argtypes = [P]
@@ -317,6 +331,52 @@ class Context:
         d = C.c_ulonglong()
         _check(lib.qcd_rng_draws(self.h, C.byref(d)))
         return d.value
+
+
+RING_COPY, RING_RCCL = 0, 1
+
+
+class Ring:
+    """A ring of slab contexts whose passes (update + halo exchange) are issued below the C-ABI (qcd_ring)."""
+
+    def __init__(self, contexts, transport=RING_COPY, rank=None, world=None, unique_id=None):
+        self.contexts = list(contexts)
+        self.h = C.c_void_p()
+        if rank is None:
+            arr = (C.c_void_p * len(self.contexts))(*[c.h for c in self.contexts])
+            _check(lib.qcd_ring_create(C.byref(self.h), arr, len(self.contexts), transport))
+        else:
+            buf = (C.c_char * 128).from_buffer_copy(unique_id)
+            _check(lib.qcd_ring_create_rank(C.byref(self.h), self.contexts[0].h, rank, world, buf, 128))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _check(lib.qcd_rccl_unique_id(buf, 128))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.qcd_ring_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def update(self, parity, direction):
+        _check(lib.qcd_ring_update(self.h, parity, direction))
+
+    def overrelax(self, parity, direction):
+        _check(lib.qcd_ring_overrelax(self.h, parity, direction))
+
+    def sweep(self, n=1):
+        _check(lib.qcd_ring_sweep(self.h, n))
+
+    def fill_halos(self):
+        _check(lib.qcd_ring_fill_halos(self.h))
+
+    def synchronize(self):
+        _check(lib.qcd_ring_synchronize(self.h))
 
 
 def prng_check(device=0, rand_series=54, lux_level=3, streams=256, samples=240):

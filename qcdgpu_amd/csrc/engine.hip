@@ -655,6 +655,20 @@ int qcd_reset_stream(qcd_ctx* c)
     return QCD_OK;
 }
 
+int qcd_get_stream(qcd_ctx* c, void** hip_stream)
+{
+    if (!c || !hip_stream) return fail(QCD_ERR_INVALID, "null argument");
+    *hip_stream = (void*)c->stream;
+    return QCD_OK;
+}
+
+int qcd_get_params(const qcd_ctx* c, qcd_params* out)
+{
+    if (!c || !out) return fail(QCD_ERR_INVALID, "null argument");
+    *out = c->p;
+    return QCD_OK;
+}
+
 int qcd_synchronize(qcd_ctx* c)
 {
     int rc = check_ctx(c, false);

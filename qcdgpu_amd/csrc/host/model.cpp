@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
 
 namespace model_HIP {
 
@@ -106,6 +107,7 @@ model::model()
 
 model::~model()
 {
+    qcd_ring_destroy(ring);
     for (auto& s : SubLat) qcd_destroy(s.ctx);
     delete PRNG0;
     free(timestart);
@@ -160,6 +162,9 @@ void model::lattice_get_init_file(char* file)
         if (!strcmp(v, "RANDSERIES") && !p.ivVarVal.empty()) rnds = p.ivVarVal;
         PRNG0->parameters_setup(v, p.ivVarVal.empty() ? p.iVarVal : p.ivVarVal[0], p.txtVarVal.c_str());
         if (!strcmp(v, "OUTPUTPATH")) path = p.txtVarVal;
+        // added key: how the edges of a BigLattice travel (default: RCCL when every part has its own device)
+        if (!strcmp(v, "TRANSPORT"))
+            ring_transport = !strcasecmp(p.txtVarVal.c_str(), "RCCL") ? QCD_RING_RCCL : QCD_RING_COPY;
         if (!strcmp(v, "FINISHPATH")) finishpath = p.txtVarVal;
         if (!strcmp(v, "GETWILSON")) get_wilson_loop = true;
         if (!strcmp(v, "GETRETRACE")) get_plaquettes_avr = true;
@@ -312,6 +317,26 @@ void model::lattice_init(void)
         check(qcd_set_profiling(s.ctx, profiling ? 1 : 0), "qcd_set_profiling");
         x0 += s.Nx;
     }
+    if (lattice_Nparts > 1) {
+        // model::UpdateEdges moves the edges through host memory, part after part (suncl.cpp:4005-4061);
+        // here the parts form a ring whose passes are issued below the C-ABI, over RCCL when every part
+        // has a GPU of its own
+        std::vector<qcd_ctx*> parts;
+        bool distinct = true;
+        for (size_t k = 0; k < SubLat.size(); k++) {
+            parts.push_back(SubLat[k].ctx);
+            for (size_t j = 0; j < k; j++) distinct = distinct && SubLat[j].desired_device != SubLat[k].desired_device;
+        }
+        int want = ring_transport >= 0 ? ring_transport : (distinct ? QCD_RING_RCCL : QCD_RING_COPY);
+        int rc = qcd_ring_create(&ring, parts.data(), (int)parts.size(), want);
+        if (rc != QCD_OK && want == QCD_RING_RCCL && ring_transport < 0) {
+            fprintf(stderr, "RCCL transport not available (%s): copying the edges instead\n", qcd_last_error());
+            want = QCD_RING_COPY;
+            rc = qcd_ring_create(&ring, parts.data(), (int)parts.size(), want);
+        }
+        check(rc, "qcd_ring_create");
+        ring_transport_name = want == QCD_RING_RCCL ? "RCCL" : "copy";
+    }
     lattice_make_header();
 }
 
@@ -334,16 +359,22 @@ void model::sweep(void)
     if (turnoff_updates) return;
     for (int parity = 1; parity >= 0; parity--)
         for (int dir = 0; dir < 4; dir++) {
-            for (auto& s : SubLat) check(qcd_update(s.ctx, parity, dir), "qcd_update");
-            UpdateEdges(dir, parity);
+            if (ring) {
+                check(qcd_ring_update(ring, parity, dir), "qcd_ring_update");
+            } else {
+                for (auto& s : SubLat) check(qcd_update(s.ctx, parity, dir), "qcd_update");
+            }
             PRNG_counter++;
         }
     // microcanonical sweeps after the heat-bath sweep (extension, NOVERRELAX = 0 by default)
     for (int n = 0; n < NOVERRELAX; n++)
         for (int parity = 1; parity >= 0; parity--)
             for (int dir = 0; dir < 4; dir++) {
-                for (auto& s : SubLat) check(qcd_overrelax(s.ctx, parity, dir), "qcd_overrelax");
-                UpdateEdges(dir, parity);
+                if (ring) {
+                    check(qcd_ring_overrelax(ring, parity, dir), "qcd_ring_overrelax");
+                } else {
+                    for (auto& s : SubLat) check(qcd_overrelax(s.ctx, parity, dir), "qcd_overrelax");
+                }
             }
 }
 

@@ -153,6 +153,11 @@ public:
     // to devices by DEVICE = {..} (several parts may share a device)
     int lattice_Nparts = 1;
     std::vector<SubLattice> SubLat;
+    // the parts as a ring below the C-ABI: a pass (update of every part + UpdateEdges) is one call.
+    // Transport: RCCL when every part has a device of its own, copies otherwise (TRANSPORT = COPY | RCCL overrides)
+    qcd_ring* ring = nullptr;
+    int ring_transport = -1;          // -1: choose; QCD_RING_COPY; QCD_RING_RCCL
+    std::string ring_transport_name;  // what the run uses, for the header
 
     data_analysis Analysis[DM_max + 1];
 

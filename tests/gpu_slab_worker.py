@@ -23,11 +23,19 @@ def main():
     dist.init_process_group(backend="gloo")
     L = cfg["L"]
     start = {0: q.START_HOT, 1: q.START_COLD, 2: q.START_GID}[cfg["ints"]]
-    lat = bl.make_rank_slab(cfg["group"], L, cfg["beta"], rank, world, 0, nhit=cfg["nhit"],
-                            rand_series=cfg["seed"], start_mode=start)
-    eng = lat.engines[0]
-    assert isinstance(eng, bl.GpuSlabEngine) and isinstance(lat.comm, bl.TorchDistComm)
-    depth = lat.boundary_depth()
+    if cfg.get("ring"):
+        # the C library's own pass over RCCL (one part per process); gloo only carries the identifier and the sums
+        lat = bl.make_rank_ring(cfg["group"], L, cfg["beta"], rank, world, 0, nhit=cfg["nhit"],
+                                rand_series=cfg["seed"], start_mode=start)
+        eng, depth = lat, 1
+        lat.comm = lat
+        lat.allreduce_sum = lat._global_sum
+    else:
+        lat = bl.make_rank_slab(cfg["group"], L, cfg["beta"], rank, world, 0, nhit=cfg["nhit"],
+                                rand_series=cfg["seed"], start_mode=start)
+        eng = lat.engines[0]
+        assert isinstance(eng, bl.GpuSlabEngine) and isinstance(lat.comm, bl.TorchDistComm)
+        depth = lat.boundary_depth()
     rows = []
     for _ in range(cfg["sweeps"]):
         lat.sweep(1)
@@ -37,7 +45,7 @@ def main():
     if rank == 0:
         with open(os.path.join(cfg["dir"], "rows.json"), "w") as f:
             json.dump({"rows": rows, "draws": int(draws[0]), "boundary_depth": depth,
-                       "split": hasattr(eng, "update_split")}, f)
+                       "split": hasattr(eng, "update_split") or bool(cfg.get("ring"))}, f)
     dist.barrier()
     dist.destroy_process_group()
 

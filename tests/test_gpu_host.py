@@ -420,3 +420,72 @@ def test_32x4_lattice_one_context_equals_eight_slabs():
     assert np.allclose(one_p, many_p, rtol=1e-13)
     assert np.allclose(one_l, many_l, rtol=1e-10, atol=1e-8)
     assert np.max(np.abs(plq - fx["sweeps"][1]["plaquette"]) / np.abs(fx["sweeps"][1]["plaquette"])) < 1e-12
+
+
+@pytest.mark.parametrize("group,L,parts,beta,nhit", [(3, (16, 4, 4, 6), [8, 4, 4], 5.8, 4), (3, (12, 4, 4, 4), [4, 8], 1.0, 12),
+                                                    (2, (8, 6, 4, 4), [2, 4, 2], 2.3, 5)])
+def test_ring_pass_below_the_c_abi_equals_uncut_lattice(group, L, parts, beta, nhit):
+    """qcd_ring: update of every part + edge exchange as one call (copy transport, all parts on the
+    one device): same configuration as the uncut lattice of the checker, link by link; parts of four
+    or more slices take the split pass (boundary slices first, interior on the side lane)."""
+    import qcdgpu_amd as q
+    lat = ol.Lattice(group, L, beta, nhit=nhit, ints=1, rng_mode=ol.RNG_PERSITE, seed=31)
+    ctxs, x0 = [], 0
+    for nx in parts:
+        c = q.Context(group=group, L=L, beta=beta, nhit=nhit, rand_series=31, x0=x0, nx_local=nx, halo=1)
+        c.init_lattice()
+        ctxs.append(c)
+        x0 += nx
+    ring = q.Ring(ctxs, q.RING_COPY)
+    try:
+        for s in range(2):
+            ring.sweep(1)
+            lat.sweep(1)
+            sums = np.sum([c.plaquette_sums() for c in ctxs], axis=0)
+            v = float(np.prod(L))
+            got = np.array([sums[0] / (3 * v), sums[1] / (3 * v), (sums[0] + sums[1]) / (6 * v)])
+            assert np.max(np.abs(got - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-12
+        for parity in (1, 0):
+            for d in range(4):
+                ring.overrelax(parity, d)
+        lat.overrelax_sweep(1)
+        assert sum(c.rng_draws() for c in ctxs) == ol.rng_draws(lat)
+        got = np.concatenate([c.download() for c in ctxs], axis=1)
+        # three sweeps of a chaotic map: rounding differences between device and host arithmetic grow
+        # from 1e-16 to 1e-12 at beta = 6 and to 1e-9 in the disordered phase at beta = 1
+        assert np.max(np.abs(got - lat.export_table())) < (1e-10 if beta > 3 else 1e-8)
+        with pytest.raises(q.QcdError):
+            ring.update(2, 0)
+    finally:
+        ring.close()
+        for c in ctxs:
+            c.close()
+        lat.close()
+
+
+@pytest.mark.parametrize("by_rank", [False, True])
+def test_ring_over_rccl_on_one_gpu(by_rank):
+    """The RCCL transport where a one-GPU box can run it: a ring of ONE part whose neighbours on
+    both sides are itself (ncclSend / ncclRecv to its own rank inside one group), made from all
+    parts of a process (ncclCommInitAll) or as rank 0 of a world of one (ncclCommInitRank with an
+    identifier).  The slab with its halos must reproduce the periodic lattice of the checker."""
+    import qcdgpu_amd as q
+    L = (8, 4, 4, 6)
+    lat = ol.Lattice(3, L, 5.7, nhit=5, ints=1, rng_mode=ol.RNG_PERSITE, seed=17)
+    c = q.Context(group=3, L=L, beta=5.7, nhit=5, rand_series=17, x0=0, nx_local=L[0], halo=1)
+    c.init_lattice()
+    ring = q.Ring([c], rank=0, world=1, unique_id=q.Ring.unique_id()) if by_rank else q.Ring([c], q.RING_RCCL)
+    try:
+        for s in range(2):
+            ring.sweep(1)
+            lat.sweep(1)
+            sums = c.plaquette_sums()
+            v = float(np.prod(L))
+            got = np.array([sums[0] / (3 * v), sums[1] / (3 * v), (sums[0] + sums[1]) / (6 * v)])
+            assert np.max(np.abs(got - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-12
+        assert c.rng_draws() == ol.rng_draws(lat)
+        assert np.max(np.abs(c.download() - lat.export_table())) < 1e-11
+    finally:
+        ring.close()
+        c.close()
+        lat.close()

@@ -62,6 +62,23 @@ def test_gpu_ranks_reproduce_uncut_lattice(world, cfg, tmp_path):
     lat.close()
 
 
+def test_rank_ring_world_of_one(tmp_path):
+    """The path an N-GPU bench run takes by default (make_rank_ring: torch.distributed over gloo hands
+    the RCCL identifier round, the C library issues passes and RCCL send/receive) with the one rank a
+    one-GPU box allows: the slab's neighbours on both sides are itself."""
+    cfg = dict(group=3, L=[8, 4, 4, 6], beta=5.8, nhit=4, seed=29, ints=1, sweeps=2, ring=True)
+    doc, links = _run(1, cfg, tmp_path)
+    lat = ol.Lattice(3, cfg["L"], cfg["beta"], nhit=4, ints=1, rng_mode=ol.RNG_PERSITE, seed=29)
+    for row in doc["rows"]:
+        lat.sweep(1)
+        want = np.concatenate([lat.plaquette(), lat.polyakov()])
+        assert np.max(np.abs(np.array(row)[:3] - want[:3]) / np.abs(want[:3])) < 1e-12
+        assert np.allclose(np.array(row)[3:], want[3:], rtol=1e-10, atol=1e-13)
+    assert doc["draws"] == ol.rng_draws(lat)
+    assert np.max(np.abs(links - lat.export_table())) < 1e-11
+    lat.close()
+
+
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher: the process starts two ranks as children and
     prints rank 0's JSON line (both ranks on device 0, gloo staging: the one-GPU rehearsal switches)."""
