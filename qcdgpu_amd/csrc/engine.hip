@@ -816,14 +816,35 @@ int qcd_reunitarize(qcd_ctx* c)
     return tm.finish();
 }
 
-static int launch_plaquette(qcd_ctx* c)
+// the plaquette kernel with its per-workgroup partial sums going to `partial`; *nparts = how many
+static int launch_plaquette_into(qcd_ctx* c, double2* partial, double2* site_vals, int* nparts)
 {
-    const dim3 grid(c->npartial), block(MEAS_BLOCK);
-    if (c->p.group == 3) hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, c->site_vals);
-    else hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, c->site_vals);
+    const dim3 block(MEAS_BLOCK);
+    if (c->p.group == 3) {
+        // x segments per thread: long enough that the links carried along x pay, short enough for the grid to fill the device
+        static const int seg_env = getenv("QCDGPU_AMD_PLAQ_XSEG") ? atoi(getenv("QCDGPU_AMD_PLAQ_XSEG")) : 0;   // diagnostic override (1: one site per thread)
+        const Geom& g = c->g;
+        const int xseg = seg_env ? seg_env : ((long)g.gslice * cdiv(g.nx, 8) >= 256L * MEAS_BLOCK ? 8 : 4);
+        if (xseg != 8 && xseg != 4) {
+            hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), dim3(c->npartial), block, 0, c->stream, c->U, c->g, partial, site_vals);
+            *nparts = c->npartial;
+            HIP_TRY(hipGetLastError());
+            return QCD_OK;
+        }
+        const int nb = cdiv((long)g.gslice * cdiv(g.nx, xseg), MEAS_BLOCK);
+        if (nb > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
+        if (xseg == 8) hipLaunchKernelGGL((k_plaquette_march<MEAS_BLOCK, 8>), dim3(nb), block, 0, c->stream, c->U, c->g, partial, site_vals);
+        else hipLaunchKernelGGL((k_plaquette_march<MEAS_BLOCK, 4>), dim3(nb), block, 0, c->stream, c->U, c->g, partial, site_vals);
+        *nparts = nb;
+    } else {
+        hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), dim3(c->npartial), block, 0, c->stream, c->U, c->g, partial, site_vals);
+        *nparts = c->npartial;
+    }
     HIP_TRY(hipGetLastError());
     return QCD_OK;
 }
+
+static int launch_plaquette(qcd_ctx* c, int* nparts) { return launch_plaquette_into(c, c->partial, c->site_vals, nparts); }
 
 int qcd_measure_plaquette_sums(qcd_ctx* c, double sums[2])
 {
@@ -831,9 +852,10 @@ int qcd_measure_plaquette_sums(qcd_ctx* c, double sums[2])
     if (rc) return rc;
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     Timed tm(c, 1);
-    if ((rc = launch_plaquette(c))) return rc;
+    int nparts = 0;
+    if ((rc = launch_plaquette(c, &nparts))) return rc;
     if ((rc = tm.finish())) return rc;
-    if ((rc = reduce_partials(c, c->npartial, 1, sums))) return rc;
+    if ((rc = reduce_partials(c, nparts, 1, sums))) return rc;
     c->sites_fresh = c->site_vals != nullptr;
     return QCD_OK;
 }
@@ -854,11 +876,9 @@ int qcd_measure_plaquette_sums_static(qcd_ctx* c, double* sums_dev)
                     c->npartial, STATIC_PARTIALS_MAX, (long)STATIC_PARTIALS_MAX * MEAS_BLOCK);
     double2* ws = (c->p.device < STATIC_MAX_DEVICES) ? g_scratch_ptr[c->p.device] : nullptr;
     if (!ws) return fail(QCD_ERR_STATE, "no static workspace on device %d", c->p.device);
-    const dim3 grid(c->npartial), block(MEAS_BLOCK);
-    if (c->p.group == 3) hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, ws, (double2*)nullptr);
-    else hipLaunchKernelGGL((k_plaquette<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, ws, (double2*)nullptr);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_reduce<MEAS_BLOCK>), dim3(1), dim3(MEAS_BLOCK), 0, c->stream, ws, c->npartial, sums_dev);
+    int nparts = 0;
+    if ((rc = launch_plaquette_into(c, ws, nullptr, &nparts))) return rc;
+    hipLaunchKernelGGL((k_reduce<MEAS_BLOCK>), dim3(1), dim3(MEAS_BLOCK), 0, c->stream, ws, nparts, sums_dev);
     HIP_TRY(hipGetLastError());
     c->timing.measure_launches++;
     return QCD_OK;
@@ -994,7 +1014,8 @@ static int measure_profile(qcd_ctx* c, int axis, double* sums, bool polyakov)
         have = false;
     }
     Timed tm(c, 1);
-    if (!have && (rc = launch_plaquette(c))) return rc;
+    int nparts_unused = 0;
+    if (!have && (rc = launch_plaquette(c, &nparts_unused))) return rc;
     hipLaunchKernelGGL((k_sites_profile<MEAS_BLOCK>), dim3(ext * chunks), dim3(MEAS_BLOCK), 0, c->stream, c->site_vals, g, axis, chunks,
                        plane, c->partial);
     HIP_TRY(hipGetLastError());

@@ -1255,12 +1255,9 @@ __device__ __forceinline__ cplx cross_c(cplx a1, cplx a2, cplx b1, cplx b2)   //
 // a = two rows of U_mu(x), d = two rows of U_nu(x) (kept by the caller: a site's four own links
 // serve three planes each), b = U_nu(x+mu), c = U_mu(x+nu) loaded here.  ob = byte offset of the
 // other parity's half of a direction's array plus the site's own offset (link_rsrc_both).
-__device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__ U, const Geom& g, const unsigned ob,
-                                                     const NbrOff& n, const int mu, const int nu,
-                                                     const rows2& a, const rows2& d)
+// the arithmetic: a, d two rows of U_mu(x), U_nu(x); rb = U_nu(x+mu), rc = U_mu(x+nu) as loaded
+__device__ __forceinline__ double retr_plaquette_su3_from(const rows2& a, const rows2& d, const raw_link& rb, const raw_link& rc)
 {
-    const raw_link rb = issue_link(link_rsrc_both<3>(U, g, nu), g, (int)(ob + (unsigned)off_fwd(n, mu)));
-    const raw_link rc = issue_link(link_rsrc_both<3>(U, g, mu), g, (int)(ob + (unsigned)off_fwd(n, nu)));
     const su3 b = as_su3(rb);
     const su3 c = as_su3(rc);
     cplx p[2][3], q[2][3];
@@ -1285,14 +1282,22 @@ __device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__
     }
     return re;
 }
+__device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__ U, const Geom& g, const unsigned ob,
+                                                     const NbrOff& n, const int mu, const int nu,
+                                                     const rows2& a, const rows2& d)
+{
+    const raw_link rb = issue_link(link_rsrc_both<3>(U, g, nu), g, (int)(ob + (unsigned)off_fwd(n, mu)));
+    const raw_link rc = issue_link(link_rsrc_both<3>(U, g, mu), g, (int)(ob + (unsigned)off_fwd(n, nu)));
+    return retr_plaquette_su3_from(a, d, rb, rc);
+}
 
-// Thread -> site for the measurement kernels: storage order with BOTH parities side by side
-// (y fastest, then z, t, x), and the workgroups dealt to the XCDs in eight contiguous runs.  A
-// link is asked for several times -- as a site's own link and as the neighbour of others -- and
-// this way the requests come from the same wave or from workgroups that run on the same XCD at
-// about the same time, so most of them find the line in that XCD's L2.  (One parity after the
-// other, as the update pass has it, puts them 100 us apart: the plaquette kernel then fetched
-// 3.4 times the lattice per call; plaquette 205 -> 158 us at 32^4.)  False: no site for this thread.
+// Thread -> site for the measurement kernels.  Both parities side by side (y fastest), and the
+// workgroups dealt to the XCDs in eight contiguous runs, so that the requests for a link -- as a
+// site's own link and as the neighbour of three others -- come from the same wave or from
+// workgroups that run on one XCD at about the same time and find the line in that XCD's L2.  (One
+// parity after the other, as the update pass has it, puts them 100 us apart: the plaquette kernel
+// then fetched 3.4 times the lattice per call; plaquette 205 -> 158 us at 32^4.)
+// False: no site for this thread.
 template <int BLOCK>
 __device__ __forceinline__ bool measurement_site(const Geom& g, Site& x)
 {
@@ -1372,6 +1377,84 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
         if (site_vals) {
             const int h = ((x.xs * g.nt + x.t) * g.nz + x.z) * g.nyh + (x.y >> 1);
             site_vals[(size_t)par * g.vh_int + h] = make_double2(spat, temp);
+        }
+    }
+    block_reduce_store<BLOCK>(spat, temp, partial);
+}
+
+// The SU(3) plaquette sums with every thread marching XSEG sites along x.  In storage order x is
+// the slowest index: the links U_y, U_z, U_t at x + xhat that the three planes containing x need
+// are 128 workgroups away from the one that loads them as its own, which is two rounds of the
+// resident workgroups -- three requests per site that never find their line in the L2.  A thread
+// that goes on to x + xhat itself keeps them: they are requested once, serve the x planes of site x
+// as neighbours and all planes of site x + xhat as its own links.  13 link requests per site instead
+// of 16 (plus 3 per segment start), and the three dropped are the ones that always missed.
+// Threads: (y, z, t) cross-section in storage order times Nx / XSEG segments; same partial /
+// site_vals outputs.  (Workgroups shaped as tiles in (z, t) instead of rows in storage order, and
+// workgroups of 512, were measured as well: 144 and 151 us per call against 141.)
+template <int BLOCK, int XSEG>
+__global__ __launch_bounds__(BLOCK) void k_plaquette_march(const double2* __restrict__ U, const Geom g,
+                                                           double2* __restrict__ partial, double2* __restrict__ site_vals)
+{
+    double spat = 0.0, temp = 0.0;
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8 : blockIdx.x;
+    int r = lb * BLOCK + (int)threadIdx.x;
+    const int seg = r / g.gslice;
+    if (seg * XSEG < g.nx) {
+        r -= seg * g.gslice;
+        Site x;
+        x.y = r % g.ny; r /= g.ny;
+        x.z = r % g.nz;
+        x.t = r / g.nz;
+        x.xs = seg * XSEG;
+        const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * 16u;
+        rows2 own[4];
+        {
+            const int par = site_parity(g, x);
+            const unsigned own_off = (par ? pbytes : 0u) + (unsigned)half_index(g, x) * 16u;
+#pragma unroll
+            for (int d = 0; d < 4; d++) own[d] = as_rows2(issue_link(link_rsrc_both<3>(U, g, d), g, (int)own_off));
+        }
+        const int steps = (g.nx - x.xs) < XSEG ? (g.nx - x.xs) : XSEG;
+#pragma unroll 1
+        for (int s = 0; s < steps; s++) {
+            const int par = site_parity(g, x);
+            const unsigned hb = (unsigned)half_index(g, x) * 16u;
+            const unsigned other_off = (par ? 0u : pbytes) + hb;
+            const NbrOff n = neighbour_offsets(g, x);
+            // the next site's y, z, t links (as this site's x neighbours), requested first
+            raw_link nxt[3];
+#pragma unroll
+            for (int d = 1; d < 4; d++) nxt[d - 1] = issue_link(link_rsrc_both<3>(U, g, d), g, (int)(other_off + (unsigned)n.f0));
+            double sp = 0.0, tp = 0.0;
+            sp += retr_plaquette_su3(U, g, other_off, n, 1, 2, own[1], own[2]);
+            tp += retr_plaquette_su3(U, g, other_off, n, 1, 3, own[1], own[3]);
+            tp += retr_plaquette_su3(U, g, other_off, n, 2, 3, own[2], own[3]);
+            // planes with x: U_x(x) U_nu(x+xhat) (U_nu(x) U_x(x+nu))^+
+            {
+                const raw_link c1 = issue_link(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f1));
+                sp += retr_plaquette_su3_from(own[0], own[1], nxt[0], c1);
+                const raw_link c2 = issue_link(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f2));
+                sp += retr_plaquette_su3_from(own[0], own[2], nxt[1], c2);
+                const raw_link c3 = issue_link(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f3));
+                tp += retr_plaquette_su3_from(own[0], own[3], nxt[2], c3);
+            }
+            if (site_vals) {
+                const int h = ((x.xs * g.nt + x.t) * g.nz + x.z) * g.nyh + (x.y >> 1);
+                site_vals[(size_t)par * g.vh_int + h] = make_double2(sp, tp);
+            }
+            spat += sp;
+            temp += tp;
+            if (s + 1 < steps) {
+                // on to x + xhat: its y, z, t links are here, its x link is requested now
+                x.xs++;
+                const int par2 = par ^ 1;
+                const unsigned own2 = (par2 ? pbytes : 0u) + (unsigned)half_index(g, x) * 16u;
+                own[0] = as_rows2(issue_link(link_rsrc_both<3>(U, g, 0), g, (int)own2));
+#pragma unroll
+                for (int d = 1; d < 4; d++) own[d] = as_rows2(nxt[d - 1]);
+            }
         }
     }
     block_reduce_store<BLOCK>(spat, temp, partial);
