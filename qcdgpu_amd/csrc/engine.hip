@@ -197,7 +197,6 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
                 return fail(QCD_ERR_STATE, "update of slices %d..%d: some of them have been updated one pass more often than others", xs_begin,
                             xs_begin + xs_count - 1);
         a.rv.cur = s0;
-        for (int k = 0; k < xs_count; k++) c->slice_slot[(xs_begin + k) % g.nx] ^= 1;
     }
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
@@ -228,6 +227,10 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
         default: QCD_LAUNCH_UPDATE(3); break;
     }
 #undef QCD_LAUNCH_UPDATE
+    HIP_TRY(hipGetLastError());
+    // the launch is in the stream: from now on the slices' generator states are in the other slot
+    if (!GID)
+        for (int k = 0; k < xs_count; k++) c->slice_slot[(xs_begin + k) % g.nx] ^= 1;
     return QCD_OK;
 }
 

@@ -550,6 +550,9 @@ static double join_double(unsigned int low, unsigned int high)
 }
 
 unsigned int model::energies_size() const { return size_align((unsigned int)ITER); }
+// lattice_energies_plq holds the plaquette sums and, with F_mu_nu, six more blocks: index1 and
+// index2, three planes each (MODEL_energies_size = 7, suncl.h:222; offsets suncl.cpp:1626-1627)
+unsigned int model::energies_size_F() const { return (get_Fmunu || get_F0mu) ? 7u * energies_size() : energies_size(); }
 unsigned int model::table_row_size() const
 {
     return size_align((unsigned int)(lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3]));
@@ -584,15 +587,15 @@ std::vector<unsigned int> model::lattice_make_bin_header(void) const   // suncl.
     split_double(PHI, r[k], r[k + 1]); k += 2;
     split_double(OMEGA, r[k], r[k + 1]); k += 2;
     r[k++] = (unsigned int)PL_level;
-    r[k++] = 1u;   // Fmunu_index1, Fmunu_index2: not measured here, the reference's defaults
-    r[k++] = 2u;
-    r[k++] = 0u;   // get_Fmunu
+    r[k++] = (unsigned int)Fmunu_index1;
+    r[k++] = (unsigned int)Fmunu_index2;
+    r[k++] = get_Fmunu ? 1u : 0u;
     r[k++] = get_actions_avr ? 1u : 0u;
     r[k++] = get_plaquettes_avr ? 1u : 0u;
     r[k++] = get_wilson_loop ? 1u : 0u;
     r[k++] = 0u;   // lattice_measurement_size_F: the reduce scratch buffer is not part of this engine's state
     r[k++] = energies_size();
-    r[k++] = energies_size();   // lattice_energies_size_F (no F_mu_nu)
+    r[k++] = energies_size_F();   // lattice_energies_size_F: seven blocks when F_mu_nu is measured (suncl.cpp:2283-2285)
     r[k++] = energies_size();   // lattice_polyakov_loop_size
     r[k++] = (unsigned int)lattice_group;
     r[k++] = (unsigned int)lattice_nd;
@@ -631,8 +634,9 @@ bool model::lattice_load_bin_header(const unsigned int* head)   // suncl.cpp:199
     PHI = join_double(head[k], head[k + 1]); k += 2;
     OMEGA = join_double(head[k], head[k + 1]); k += 2;
     PL_level = (int)head[k++];
-    k += 2;   // Fmunu indices
-    if (head[k++] != 0u) return false;   // F_mu_nu sections are not written or read by this engine
+    Fmunu_index1 = (int)head[k++];
+    Fmunu_index2 = (int)head[k++];
+    get_Fmunu = head[k++] != 0;          // (F0MU is not in the header: the run's init file says so, as for the reference)
     get_actions_avr = head[k++] != 0;
     get_plaquettes_avr = head[k++] != 0;
     get_wilson_loop = head[k++] != 0;
@@ -674,7 +678,12 @@ void model::lattice_save_state(void)
         fwrite(sec.data(), 2 * sizeof(double), es, stream);
     };
     write_pairs(act_[0], act_[1], 3.0 * v);                               // lattice_energies: S x its denominator (suncl.cpp:1340-1348)
-    if (get_plaquettes_avr) write_pairs(plq_raw_[0], plq_raw_[1], 1.0);   // lattice_energies_plq: lattice sums
+    if (get_plaquettes_avr || get_Fmunu || get_F0mu) {                    // lattice_energies_plq (suncl.cpp:1892): lattice sums
+        write_pairs(plq_raw_[0], plq_raw_[1], 1.0);
+        if (get_Fmunu || get_F0mu)                                        // blocks 1-3: index1, blocks 4-6: index2, per plane (re, im)
+            for (int a = 0; a < 2; a++)
+                for (int pl = 0; pl < 3; pl++) write_pairs(fmunu_[6 * a + 2 * pl], fmunu_[6 * a + 2 * pl + 1], v);
+    }
     if (get_wilson_loop) {                                                // lattice_wilson_loop: doubles, sums over 3V
         std::vector<double> w((size_t)es, 0.0);
         for (int i = 0; i < ITER_counter && i < ITER; i++) w[i] = wl_[i] * 3.0 * v;
@@ -765,6 +774,24 @@ void model::lattice_load_state(void)
     }
     const double v = (double)lattice_full_size[0] * lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
     const double g = lattice_group;
+    {
+        // the sections this run expects, and the link table behind them, must fit the file: a file written
+        // with other observable switches has its link table at another offset
+        const bool plq_sec = get_plaquettes_avr || get_Fmunu || get_F0mu;
+        unsigned long long need = BIN_HEADER_SIZE * sizeof(unsigned int) + 16ull * state_sizes_[0] + 16ull * state_sizes_[1];
+        if (plq_sec) need += 16ull * state_sizes_[2];
+        if (get_wilson_loop) need += 8ull * state_sizes_[1];
+        if (PL_level > 0) need += 16ull * state_sizes_[3];
+        need += 32ull * ((lattice_group == 3) ? 12 : 4) * table_row_size();
+        const long at = ftell(stream);
+        fseek(stream, 0, SEEK_END);
+        const unsigned long long have = (unsigned long long)ftell(stream);
+        fseek(stream, at, SEEK_SET);
+        if (have < need) {
+            fclose(stream);
+            throw model_error("state file " + file + " is shorter than its header and this run's observable switches imply");
+        }
+    }
     std::vector<double> sec;
     auto read_pairs = [&](unsigned int count, std::vector<double>* a, std::vector<double>* b) {
         sec.assign(2 * (size_t)count, 0.0);
@@ -777,8 +804,23 @@ void model::lattice_load_state(void)
     std::vector<double> s_raw[2] = {std::vector<double>(ITER, 0.0), std::vector<double>(ITER, 0.0)};
     read_pairs(state_sizes_[0], nullptr, nullptr);                                      // lattice_measurement
     read_pairs(state_sizes_[1], &s_raw[0], &s_raw[1]);                                  // lattice_energies
-    if (get_plaquettes_avr) read_pairs(state_sizes_[2], &plq_raw_[0], &plq_raw_[1]);    // lattice_energies_plq
-    else
+    const bool plq_section = get_plaquettes_avr || get_Fmunu || get_F0mu;               // suncl.cpp:2063
+    if (plq_section) {                                                                  // lattice_energies_plq
+        const bool with_F = (get_Fmunu || get_F0mu) && state_sizes_[2] == 7u * state_sizes_[1];
+        const unsigned int blk = with_F ? state_sizes_[1] : state_sizes_[2];
+        read_pairs(blk, &plq_raw_[0], &plq_raw_[1]);
+        if (with_F)
+            for (int a = 0; a < 2; a++)
+                for (int pl = 0; pl < 3; pl++) {
+                    std::vector<double> re(ITER, 0.0), im(ITER, 0.0);
+                    read_pairs(blk, &re, &im);
+                    for (int i = 0; i < ITER_counter && i < ITER && !fmunu_[0].empty(); i++) {
+                        fmunu_[6 * a + 2 * pl][i] = re[i] / v;
+                        fmunu_[6 * a + 2 * pl + 1][i] = im[i] / v;
+                    }
+                }
+    }
+    if (!plq_section)
         for (int i = 0; i < ITER_counter && i < ITER; i++)   // plaquette sums back from S = beta (1 - Plq / N)
             for (int c = 0; c < 2; c++) plq_raw_[c][i] = 3.0 * v * g * (1.0 - s_raw[c][i] / (3.0 * v) / BETA);
     if (get_wilson_loop) {                                                              // lattice_wilson_loop
@@ -886,7 +928,6 @@ void model::lattice_simulate(void)
     for (int i = 0; i < 4; i++) pl_raw_[i].assign(ITER, 0.0);
     wl_.assign(ITER, 0.0);
     for (int i = 0; i < 12; i++) fmunu_[i].assign((get_Fmunu || get_F0mu) ? ITER : 0, 0.0);
-    if (INIT == 0 && (get_Fmunu || get_F0mu)) throw model_error("state files do not carry the F_mu_nu series: continue without FMUNU / F0MU");
     for (int a = 0; a < 3; a++) {
         s_diff_[a].assign(get_actions_diff ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);
         pl_diff_[a].assign(PL_level > 2 ? (size_t)lattice_full_size[a] * ITER : 0, 0.0);

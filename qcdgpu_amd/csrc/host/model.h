@@ -206,6 +206,7 @@ private:
     std::vector<unsigned int> lattice_make_bin_header(void) const;
     bool lattice_load_bin_header(const unsigned int* head);
     unsigned int energies_size() const;
+    unsigned int energies_size_F() const;
     unsigned int table_row_size() const;
     time_t last_save_ = 0;
     unsigned int state_sizes_[4] = {0, 0, 0, 0};   // section lengths read from a state file's header

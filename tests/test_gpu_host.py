@@ -489,3 +489,40 @@ def test_ring_over_rccl_on_one_gpu(by_rank):
         ring.close()
         c.close()
         lat.close()
+
+
+def test_cli_state_file_with_fmunu_sections(tmp_path):
+    """The state file with F0MU = 1 and no plaquette average: the reference writes its
+    lattice_energies_plq section whenever plaquettes OR either field tensor is measured
+    (SU(N)/suncl/suncl.cpp:1892, 2063), seven blocks long with the tensor (MODEL_energies_size),
+    and the link table behind it.  Header words, the table's offset, an exact resume, and a file
+    that is too short for the switches of the run that loads it."""
+    import shutil
+    import struct
+    keys = dict(GROUP=3, ND=4, L1=4, L2=4, L3=4, L4=6, BETA=5.8, NHIT=4, INTS=1, PRNG="RANLUX3",
+                RANDSERIES=41, NAV=1, ITER=5, NITER=1, F0MU=1, FMUNU2=1, FMUNU6=1)
+    _, fields, full, _ = _run(tmp_path / "a", keys)
+    assert any(f.startswith("Fmunu_xt_2") for f in fields) and any(f.startswith("Fmunu_xt_6") for f in fields)
+    _, _, none, out = _run(tmp_path / "b", keys, args=["--save-state", "--save-every", "1e9", "--stop-at", "3"])
+    qcg = re.findall(r"state file: (\S+)", out)[-1]
+    raw = open(qcg, "rb").read()
+    head = struct.unpack("<64I", raw[:256])
+    assert head[26:29] == (2, 6, 0)            # Fmunu_index1, Fmunu_index2, get_Fmunu (the E field is F0MU: not a header word)
+    es = head[33]
+    assert head[32:36] == (0, es, 7 * es, es)  # measurement, energies, energies_plq (7 blocks), Polyakov loop
+    sites, rs = 4 * 4 * 4 * 6, 512
+    off = 256 + 16 * es + 16 * 7 * es + 16 * es          # header, energies, energies_plq, Polyakov loop
+    table = np.frombuffer(raw[off:off + 12 * rs * 32], dtype=np.float64).reshape(12, rs, 4)
+    u = table[0:4, :sites, :3] + 1j * table[4:8, :sites, :3]
+    assert np.max(np.abs(np.sum(np.abs(u) ** 2, axis=2) - 1)) < 1e-14
+    assert raw[off + 12 * rs * 32:off + 12 * rs * 32 + 7] == b"QCDRLX1"
+    (tmp_path / "c").mkdir()
+    shutil.copy(qcg, tmp_path / "c" / "s.qcg")
+    _, _, resumed, _ = _run(tmp_path / "c", keys, args=["--load", "s.qcg"])
+    assert np.array_equal(resumed, full)
+    # a file cut inside its link table is refused, not read at a wrong offset
+    (tmp_path / "d").mkdir()
+    with open(tmp_path / "d" / "s.qcg", "wb") as f:
+        f.write(raw[:off + 1000])
+    with pytest.raises(AssertionError):
+        _run(tmp_path / "d", keys, args=["--load", "s.qcg"])
