@@ -423,11 +423,13 @@ def test_32x4_lattice_one_context_equals_eight_slabs():
 
 
 @pytest.mark.parametrize("group,L,parts,beta,nhit", [(3, (16, 4, 4, 6), [8, 4, 4], 5.8, 4), (3, (12, 4, 4, 4), [4, 8], 1.0, 12),
-                                                    (2, (8, 6, 4, 4), [2, 4, 2], 2.3, 5)])
+                                                    (2, (8, 6, 4, 4), [2, 4, 2], 2.3, 5), (3, (8, 4, 4, 4), [3, 5], 5.8, 4),
+                                                    (3, (8, 4, 6, 4), [1, 7], 5.6, 3)])
 def test_ring_pass_below_the_c_abi_equals_uncut_lattice(group, L, parts, beta, nhit):
     """qcd_ring: update of every part + edge exchange as one call (copy transport, all parts on the
     one device): same configuration as the uncut lattice of the checker, link by link; parts of four
-    or more slices take the split pass (boundary slices first, interior on the side lane)."""
+    or more slices take the split pass (boundary slices first, interior on the side lane).  Parts may
+    be of odd width, one slice included: only the uncut extents have to be even."""
     import qcdgpu_amd as q
     lat = ol.Lattice(group, L, beta, nhit=nhit, ints=1, rng_mode=ol.RNG_PERSITE, seed=31)
     ctxs, x0 = [], 0

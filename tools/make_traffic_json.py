@@ -13,7 +13,7 @@ src, dst = sys.argv[1], sys.argv[2]
 pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
 per = {}
 for k, v in pmc.items():
-    if "k_update<" in k and "redo" not in k:
+    if "k_update" in k and "redo" not in k:
         per[k] = {"fetch_bytes": 2 * 1024.0 * v["FETCH_SIZE"]["mean_per_dispatch"],
                   "write_bytes": 1024.0 * v["WRITE_SIZE"]["mean_per_dispatch"]}
 fetch = sum(p["fetch_bytes"] for p in per.values()) / len(per)
@@ -33,6 +33,37 @@ out = {
                     "fetch_ratio_reported_over_true": 1024.0 * kf / true_bytes,
                     "write_ratio_reported_over_true": 1024.0 * kw / true_bytes},
 }
+# the O(N) update pass, when tools/profile_on.sh ran into <src>/on
+on_dir = os.path.join(src, "on")
+if os.path.exists(os.path.join(on_dir, "fetch.json")):
+    f = json.load(open(os.path.join(on_dir, "fetch.json")))
+    w = json.load(open(os.path.join(on_dir, "write.json")))
+    i = json.load(open(os.path.join(on_dir, "insts.json")))
+    key = [k for k in f if "k_on_update<float" in k][0]
+    fb = 2 * 1024.0 * f[key]["FETCH_SIZE"]["mean_per_dispatch"]
+    wb = 1024.0 * w[key]["WRITE_SIZE"]["mean_per_dispatch"]
+    out["on_hbm_bytes_per_update_launch"] = fb + wb
+    out["on_fetch_bytes"], out["on_write_bytes"] = fb, wb
+    valu = i[key]["SQ_INSTS_VALU"]["mean_per_dispatch"]
+    out["on_valu_wave_instructions_per_launch"] = valu
+    out["on_limited_by"] = ("vector-instruction issue: %.0f M wavefront instructions per pass (logarithms, exponential, generator), "
+                            "one per SIMD every %.1f cycles of the 2.4 GHz nominal clock at the measured pass time; the bytes moved are "
+                            "generator state, not field values" % (valu / 1e6, 0))
+    for name in ("fetch", "write", "insts", "busy"):
+        if os.path.exists(os.path.join(on_dir, name + ".json")):
+            os.makedirs(dst, exist_ok=True)
+            shutil.copy(os.path.join(on_dir, name + ".json"), os.path.join(dst, "on64_pmc_%s.json" % name))
+    for fn in os.listdir(os.path.join(on_dir, "trace")) if os.path.isdir(os.path.join(on_dir, "trace")) else []:
+        if fn.endswith("kernel_stats.csv"):
+            shutil.copy(os.path.join(on_dir, "trace", fn), os.path.join(dst, "on64_kernel_stats.csv"))
+            import csv
+            for row in csv.DictReader(open(os.path.join(on_dir, "trace", fn))):
+                if "k_on_update<float" in row["Name"]:
+                    avg_ns = float(row["AverageNs"])
+                    cyc = avg_ns * 2.4 * 1024 / valu
+                    out["on_limited_by"] = ("vector-instruction issue: %.0f M wavefront instructions per pass (logarithms, exponential, "
+                                            "generator) in %.0f us = one per SIMD every %.1f cycles of the 2.4 GHz nominal clock; the bytes "
+                                            "moved are generator state, not field values" % (valu / 1e6, avg_ns / 1e3, cyc))
 json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), "roofline_traffic.json"), "w"), indent=1)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "pmc_summary.json"))
