@@ -203,6 +203,23 @@ int qcd_rng_state_upload(qcd_ctx *ctx, const void *host, size_t bytes);
 size_t qcd_halo_bytes(const qcd_ctx *ctx);
 int    qcd_halo_pack(qcd_ctx *ctx, int side, int dir, int parity, void *dev_buf);
 int    qcd_halo_unpack(qcd_ctx *ctx, int side, int dir, int parity, const void *dev_buf);
+/* One pass over the links (parity, dir) of a slab in ONE launch that starts with the `edge` slices
+ * next to each face and goes on with the interior; as soon as the edge slices are stored and
+ * visible to the device it writes `value` to *signal, a 32-bit word of signal memory
+ * (hipExtMallocWithFlags(.., 8, hipMallocSignalMemory)) on which another stream waits with
+ * hipStreamWaitValue32 before it packs the boundary slices -- the messages of a pass then travel
+ * beside the rest of the same launch.  QCD_ERR_UNSUPPORTED (and nothing launched) when this pass
+ * would not run as the kernel that can signal (SU(2), gid mode, small or ragged slabs): the caller
+ * falls back to two launches (qcd_update_range).  No counterpart in the reference, whose parts are
+ * updated whole before their edges are copied (suncl.cpp:5026-5138). */
+int    qcd_update_signal_edges(qcd_ctx *ctx, int parity, int dir, int edge, void *signal, unsigned value);
+
+/* Where a message lies in the lattice itself, for a transport that moves it without packing: the
+ * links (dir, parity) of the first (side 0) / last (side 1) owned slice (owned = 1) or of the
+ * left (0) / right (1) halo slice (owned = 0) are `*pieces` runs of `*piece_bytes` bytes,
+ * `*pitch_bytes` apart, the first at `*first`; run k is piece k of qcd_halo_pack's buffer. */
+int    qcd_halo_region(qcd_ctx *ctx, int side, int owned, int dir, int parity, void **first,
+                       size_t *piece_bytes, size_t *pitch_bytes, int *pieces);
 
 /* UpdateEdges between two parts that live in ONE process (the reference's own single-process
  * BigLattice, suncl.cpp:4005-4061): boundary slice `pack_side` of src -> halo `recv_side` of dst,
@@ -212,8 +229,9 @@ int    qcd_halo_copy(qcd_ctx *src, int pack_side, qcd_ctx *dst, int recv_side, i
 /* The BIGLAT branch of model::lattice_simulate (suncl.cpp:5026-5138): per (parity, direction) a
  * kernel_run(sun_update_*) for every part followed by model::UpdateEdges(dir) (suncl.cpp:4005-4061).
  * A ring holds the parts (contexts with halo = 1, in ring order) and issues such a pass in ONE call
- * without a host synchronisation: every part updates the slice next to either face first, packs
- * and sends them while the rest of its slab is updated beside that, receives and unpacks.
+ * without a host synchronisation: every part updates the slices next to its two faces first
+ * (one launch), then the rest of its slab (a second launch behind it on the same stream); the
+ * boundary slices are packed, sent, received and unpacked on a stream beside the second launch.
  *   QCD_RING_COPY: all parts in this process; messages by device-to-device / peer copies
  *                  (several parts may share a device: the reference's devParts, QCDGPU.cpp:129-134);
  *   QCD_RING_RCCL: ncclSend / ncclRecv between ring neighbours (xGMI between the GPUs of a node);
@@ -236,6 +254,9 @@ int  qcd_ring_overrelax(qcd_ring *ring, int parity, int dir);
 int  qcd_ring_sweep(qcd_ring *ring, int n);
 int  qcd_ring_fill_halos(qcd_ring *ring);
 int  qcd_ring_synchronize(qcd_ring *ring);
+/* how many passes of parts went out as one launch with the edge signal (qcd_update_signal_edges)
+ * so far; the others took two launches */
+int  qcd_ring_one_launch_passes(qcd_ring *ring, unsigned long long *n);
 
 /* device_select / device_initialize (clinterface.cpp:345-459): what the host needs to know */
 int qcd_device_count(int *count);

@@ -46,7 +46,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_init_lattice", "qcd_update", "qcd_sweep", "qcd_reunitarize",
            "qcd_measure_plaquette", "qcd_measure_action", "qcd_measure_polyakov",
            "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums", "qcd_upload", "qcd_download",
-           "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_halo_copy",
+           "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_update_signal_edges", "qcd_halo_region", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
            "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
@@ -56,7 +56,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
            "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params",
            "qcd_ring_create", "qcd_rccl_unique_id", "qcd_ring_create_rank", "qcd_ring_destroy", "qcd_ring_update",
-           "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize"]
+           "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize", "qcd_ring_one_launch_passes"]
 
 
 def _load():
@@ -101,12 +101,15 @@ def _load():
     lib.qcd_ring_sweep.argtypes = [P, I]
     lib.qcd_ring_fill_halos.argtypes = [P]
     lib.qcd_ring_synchronize.argtypes = [P]
+    lib.qcd_ring_one_launch_passes.argtypes = [P, C.POINTER(C.c_ulonglong)]
     lib.qcd_upload.argtypes = [P, P, C.c_size_t, I]
     lib.qcd_download.argtypes = [P, P, C.c_size_t, I]
     lib.qcd_halo_bytes.argtypes = [P]
     lib.qcd_halo_bytes.restype = C.c_size_t
     lib.qcd_halo_pack.argtypes = [P, I, I, I, P]
     lib.qcd_halo_unpack.argtypes = [P, I, I, I, P]
+    lib.qcd_halo_region.argtypes = [P, I, I, I, I, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(I)]
+    lib.qcd_update_signal_edges.argtypes = [P, I, I, I, P, C.c_uint]
     lib.qcd_halo_copy.argtypes = [P, I, P, I, I, I]
     lib.qcd_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.qcd_device_name.argtypes = [I, C.c_char_p, C.c_size_t]
@@ -377,6 +380,12 @@ class Ring:
 
     def synchronize(self):
         _check(lib.qcd_ring_synchronize(self.h))
+
+    def one_launch_passes(self):
+        """Passes of parts issued as one launch with the in-kernel edge signal so far."""
+        n = C.c_ulonglong(0)
+        _check(lib.qcd_ring_one_launch_passes(self.h, C.byref(n)))
+        return int(n.value)
 
 
 def prng_check(device=0, rand_series=54, lux_level=3, streams=256, samples=240):

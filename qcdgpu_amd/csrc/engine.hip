@@ -98,6 +98,10 @@ struct qcd_ctx {
     int ncomp;
     int upd_grid;             // workgroups per update launch (0: one per block of sites)
     int gh_grid;              // workgroups (one per CU) of the gather / heat-bath pair kernel (0: not available)
+    // qcd_update_signal_edges: what the next update launch signals (slices = 0: nothing), and the
+    // device word its edge blocks count in
+    struct { int slices; unsigned* flag; unsigned seq; } edge_sig = {0, nullptr, 0u};
+    unsigned* edge_count = nullptr;
     int gh_mode;              // 0 never, 1 when the launch has at least 8 * gh_grid blocks, 2 whenever possible
     hipStream_t own_stream, stream;
     double2* U;
@@ -201,12 +205,30 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
+    a.edge_local = 0;
+    a.edge_total = 0u;
+    a.edge_seq = 0u;
+    a.edge_count = nullptr;
+    a.edge_flag = nullptr;
+    const int edge_slices = c->edge_sig.slices;
+    c->edge_sig.slices = 0;
     bool paired = false;   // launched as the gather / heat-bath pair kernel
     if constexpr (GROUP == 3 && !GID && UPD_BLOCK == 64) {
         // it has no code for partly filled blocks
         const bool full = ((long)g.unx * g.region_h) % UPD_BLOCK == 0 && g.tz == 0;
         if (c->gh_grid > 0 && full && (c->gh_mode == 2 || (c->gh_mode == 1 && nblocks >= 2 * GH_SIDE * c->gh_grid))) {
             paired = true;
+            if (edge_slices > 0) {
+                // the launch starts at the last `edge_slices` slices and wraps to the first ones: with
+                // whole blocks per slice the first blocks of every region are exactly those slices
+                if (g.region_h % UPD_BLOCK != 0 || !c->edge_count)
+                    return fail(QCD_ERR_UNSUPPORTED, "edge signal: a slice of this lattice is not a whole number of blocks per region");
+                a.edge_local = 2 * edge_slices * (int)(g.region_h / UPD_BLOCK);
+                a.edge_total = (unsigned)a.edge_local * (unsigned)regions;
+                a.edge_seq = c->edge_sig.seq;
+                a.edge_count = c->edge_count;
+                a.edge_flag = c->edge_sig.flag;
+            }
             const dim3 ggrid(c->gh_grid), gblock(512);
 #define QCD_LAUNCH_GH(D) hipLaunchKernelGGL((k_update_gh<D, NSKIP, GH_TEAMS>), ggrid, gblock, 0, stream, a)
             switch (dir) {
@@ -218,6 +240,9 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
 #undef QCD_LAUNCH_GH
         }
     }
+    if (edge_slices > 0 && !paired)
+        return fail(QCD_ERR_UNSUPPORTED, "edge signal: this pass does not run as the kernel that has it (SU(3), per-thread streams, at least %d blocks)",
+                    2 * GH_SIDE * c->gh_grid);
 #define QCD_LAUNCH_UPDATE(D) \
     hipLaunchKernelGGL((k_update<GROUP, D, GID, NSKIP, UPD_BLOCK>), grid, block, 0, stream, a)
     if (!paired) switch (dir) {
@@ -597,8 +622,11 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipHostMalloc(&c->result_host, c->result_len * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(result)");
     if (rc == QCD_OK) tryhip(hipHostGetDevicePointer((void**)&c->result_host_dev, c->result_host, 0), "hipHostGetDevicePointer(result)");
     tryhip(hipMalloc(&c->draws_dev, DRAWS_BYTES), "hipMalloc(draws)");
-    if (g.halo) {   // slabs only: the side lane of qcd_update_split
-        tryhip(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), "hipStreamCreate(side lane)");
+    if (g.halo) {   // slabs only: the counter of qcd_update_signal_edges, the side lane of qcd_update_split
+        tryhip(hipMalloc((void**)&c->edge_count, sizeof(unsigned)), "hipMalloc(edge counter)");
+        if (c->edge_count) tryhip(hipMemset(c->edge_count, 0, sizeof(unsigned)), "hipMemset(edge counter)");
+        // (the side stream itself is made by the first qcd_update_split: a process has few hardware queues,
+        // four by default, and streams beyond that share them -- what shares a queue runs in turn)
         tryhip(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming), "hipEventCreate");
         tryhip(hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming), "hipEventCreate");
     }
@@ -626,6 +654,7 @@ void qcd_destroy(qcd_ctx* c)
     (void)hipFree(c->loops);
     (void)hipFree(c->site_vals);
     (void)hipFree(c->draws_dev);
+    if (c->edge_count) (void)hipFree(c->edge_count);
     if (c->side_stream) {
         (void)hipStreamSynchronize(c->side_stream);
         (void)hipStreamDestroy(c->side_stream);
@@ -741,6 +770,25 @@ int qcd_update_range(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_count
     return launch_update(c, parity, dir, xs_begin, xs_count);
 }
 
+int qcd_update_signal_edges(qcd_ctx* c, int parity, int dir, int edge, void* signal, unsigned value)
+{
+    int rc = check_ctx(c, true);
+    if (rc) return rc;
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    const int nx = c->g.nx;
+    if (!c->g.halo) return fail(QCD_ERR_STATE, "context has no halo slices");
+    if (edge < 1 || 2 * edge >= nx) return fail(QCD_ERR_INVALID, "%d edge slices per face of %d owned slices", edge, nx);
+    if (!signal) return fail(QCD_ERR_INVALID, "null signal");
+    if (c->profiling) return fail(QCD_ERR_UNSUPPORTED, "edge signal: not with per-launch profiling");
+    c->edge_sig.slices = edge;
+    c->edge_sig.flag = (unsigned*)signal;
+    c->edge_sig.seq = value;
+    rc = launch_update(c, parity, dir, nx - edge, nx);   // the whole slab, starting at the last `edge` slices
+    c->edge_sig.slices = 0;
+    return rc;
+}
+
 int qcd_update_split(qcd_ctx* c, int parity, int dir, int first_begin, int first_count)
 {
     int rc = check_ctx(c, true);
@@ -752,6 +800,7 @@ int qcd_update_split(qcd_ctx* c, int parity, int dir, int first_begin, int first
         return fail(QCD_ERR_INVALID, "slice range %d + %d of %d owned slices", first_begin, first_count, nx);
     if (first_count == nx) return launch_update(c, parity, dir, first_begin, first_count);
     const int rest_begin = (first_begin + first_count) % nx, rest_count = nx - first_count;
+    if (c->g.halo && !c->side_stream && !c->profiling) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     if (!c->side_stream || c->profiling) {
         // no side lane (a context without halos), or per-launch timing asked for: one after the other
         rc = launch_update(c, parity, dir, first_begin, first_count);
@@ -1196,6 +1245,7 @@ static int halo_op(qcd_ctx* c, int side, int dir, int parity, void* buf, bool pa
 {
     int rc = check_ctx(c, true, false);
     if (rc) return rc;
+    const hipStream_t stream = c->stream;
     if (!c->g.halo) return fail(QCD_ERR_STATE, "context has no halo slices");
     if (side != 0 && side != 1) return fail(QCD_ERR_INVALID, "side %d", side);
     if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
@@ -1206,11 +1256,11 @@ static int halo_op(qcd_ctx* c, int side, int dir, int parity, void* buf, bool pa
     Timed tm(c, 2);
     const dim3 grid(cdiv((long)c->ncomp * c->g.slice_h, MEAS_BLOCK)), block(MEAS_BLOCK);
     if (c->p.group == 3) {
-        if (pack) hipLaunchKernelGGL((k_halo<3, true, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
-        else hipLaunchKernelGGL((k_halo<3, false, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        if (pack) hipLaunchKernelGGL((k_halo<3, true, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        else hipLaunchKernelGGL((k_halo<3, false, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
     } else {
-        if (pack) hipLaunchKernelGGL((k_halo<2, true, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
-        else hipLaunchKernelGGL((k_halo<2, false, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        if (pack) hipLaunchKernelGGL((k_halo<2, true, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        else hipLaunchKernelGGL((k_halo<2, false, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
     }
     return tm.finish();
 }
@@ -1223,6 +1273,24 @@ int qcd_halo_pack(qcd_ctx* c, int side, int dir, int parity, void* dev_buf)
 int qcd_halo_unpack(qcd_ctx* c, int side, int dir, int parity, const void* dev_buf)
 {
     return halo_op(c, side, dir, parity, const_cast<void*>(dev_buf), false);
+}
+
+int qcd_halo_region(qcd_ctx* c, int side, int owned, int dir, int parity, void** first, size_t* piece_bytes, size_t* pitch_bytes, int* pieces)
+{
+    if (!c || !first || !piece_bytes || !pitch_bytes || !pieces) return fail(QCD_ERR_INVALID, "null argument");
+    if (!c->g.halo) return fail(QCD_ERR_STATE, "context has no halo slices");
+    if (side != 0 && side != 1) return fail(QCD_ERR_INVALID, "side %d", side);
+    if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
+    // stored slices: 0 = left halo, 1..nx = owned, nx+1 = right halo; a slice of one component
+    // array is one run of slice_h elements (x is the slowest index of a site's half index)
+    const int slice = owned ? (side == 0 ? 1 : c->g.nx) : (side == 0 ? 0 : c->g.nx + 1);
+    const size_t base = c->p.group == 3 ? comp_base<3>(c->g, dir, parity) : comp_base<2>(c->g, dir, parity);
+    *first = (void*)(c->U + base + (size_t)slice * c->g.slice_h);
+    *piece_bytes = (size_t)c->g.slice_h * sizeof(double2);
+    *pitch_bytes = (size_t)c->g.vh_alloc * sizeof(double2);
+    *pieces = c->ncomp;
+    return QCD_OK;
 }
 
 static int edge_buffers(qcd_ctx* c)

@@ -847,7 +847,34 @@ struct UpdArgs {
     const float* gidr;
     unsigned long long* draws;
     int nblocks;   // blocks of BLOCK sites in the pass; workgroup b takes b, b + gridDim.x, ...
+    // Edge signal of a slab pass (edge_local = 0: none).  The first edge_local blocks of every
+    // region are the slices next to the slab's two faces (the launch starts there); when the last
+    // of them is stored and visible to the device, edge_seq is written to *edge_flag, on which
+    // the stream that packs the boundary slices waits while this launch goes on with the interior.
+    int edge_local;
+    unsigned edge_total;     // edge blocks of the launch, all regions
+    unsigned edge_seq;
+    unsigned* edge_count;    // device memory, zero between launches
+    unsigned* edge_flag;     // signal memory (hipMallocSignalMemory)
 };
+
+// called by a whole wavefront after the stores of an edge block
+__device__ __forceinline__ void edge_block_done(const UpdArgs& a, const int lane)
+{
+    // The links of an edge block were stored with write-through (STORE_AUX_THROUGH): when the
+    // wavefront's stores are acknowledged they are in memory, where the packing kernel -- on any
+    // XCD, starting with an L2 that holds nothing of them -- finds them.  (A release fence at device
+    // scope would do as well but writes back the whole L2 of the XCD each time: 512 of them made a
+    // 32^4 pass 40 us longer.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const unsigned done = __hip_atomic_fetch_add(a.edge_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (done == a.edge_total) {
+            __hip_atomic_store(a.edge_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.edge_flag, a.edge_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK>
 __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs args_by_value)
@@ -1192,7 +1219,12 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
             su3 Ul = as_su3(own);
             update_link<false>(Ul, A, a.beta_eff, a.beta_inv, a.nhit, rs, fm);
             used += (unsigned long long)rs.close();
-            store_link_buf(r_own, g, cur.hb, Ul);
+            if (a.edge_local > 0 && wb / (g.nzr * g.ntr) < a.edge_local) {
+                store_link_buf<STORE_AUX_THROUGH>(r_own, g, cur.hb, Ul);
+                edge_block_done(a, lane);
+            } else {
+                store_link_buf(r_own, g, cur.hb, Ul);
+            }
         }
         used = block_sum_u64<64>(used);
         if (lane == 0 && used) atomicAdd(a.draws + (size_t)((blockIdx.x * GH_SIDE + member) % DRAW_SLOTS) * DRAW_SLOT_STRIDE, used);

@@ -151,7 +151,7 @@ __device__ __forceinline__ Site bwd(const Geom& g, Site s, int dir)
 }
 
 template <int GROUP>
-__device__ __forceinline__ size_t comp_base(const Geom& g, int dir, int par)
+__host__ __device__ __forceinline__ size_t comp_base(const Geom& g, int dir, int par)
 {
     return (size_t)((dir * 2 + par) * ncomp<GROUP>::value) * (size_t)g.vh_alloc;
 }
@@ -257,13 +257,17 @@ __device__ __forceinline__ su2 load_link_buf(__amdgpu_buffer_rsrc_t r, const Geo
 #ifndef QCD_STORE_AUX
 #define QCD_STORE_AUX 2
 #endif
+template <int AUX = QCD_STORE_AUX>
 __device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, const su3& m)
 {
 #pragma unroll
     for (int c = 0; c < 6; c++)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im)),
-                                               r, byte_off, c * g.vh_alloc * 16, QCD_STORE_AUX);
+                                               r, byte_off, c * g.vh_alloc * 16, AUX);
 }
+// cache policy sc0 | sc1: the store is written through to memory, so that once the wavefront's
+// store count is back at zero a kernel that starts on any XCD reads the new value
+constexpr int STORE_AUX_THROUGH = 1 | 16;
 __device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, const su2& m)
 {
 #pragma unroll

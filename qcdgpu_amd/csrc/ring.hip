@@ -4,16 +4,30 @@
 // one part after the other (model::lattice_simulate with BIGLAT, SU(N)/suncl/suncl.cpp:5026-5138;
 // model::UpdateEdges, :4005-4061).  Here a pass over (parity, direction) is issued for all parts
 // of the ring in one call, without a host synchronisation:
-//     1. every part updates the slice next to either face first (qcd_update_split: the rest of the
-//        slab follows on the part's side lane, beside everything below);
-//     2. every part packs what its neighbours' halos need: its last slice for the right
-//        neighbour (all directions), its first slice for the left one (not for X links: nothing
-//        reads U_x one slice to the right);
-//     3. the messages travel -- device-to-device copies inside one process (QCD_RING_COPY), or
-//        RCCL send/receive between ring neighbours on a stream of its own per part (QCD_RING_RCCL:
-//        xGMI between GPUs; one ncclGroup per pass);
-//     4. every part unpacks into its halo slices.
-// The next pass of a part waits for its side lane by itself (every non-halo entry point does).
+//     1. on its context's stream every part updates its slab in ONE launch that starts with the
+//        slices next to its two faces and writes a word when those are done and in memory
+//        (qcd_update_signal_edges; slabs too small for that kernel, SU(2) and gid runs: two launches,
+//        boundary slices first);
+//     2. on a lane beside that stream the part waits for that word (hipStreamWaitValue32) -- from
+//        then on its boundary slices can be read while the launch goes on with the interior;
+//     3. the messages travel: last slice -> right neighbour's left halo (all directions), first
+//        slice -> left neighbour's right halo (not for X links: nothing reads U_x one slice to the
+//        right).  A boundary slice of the links of one direction and parity is six (SU(2): two)
+//        contiguous runs, and so is the halo slice it goes to.  QCD_RING_COPY: the receiver's lane
+//        copies them from lattice to lattice (one kernel for both halos on the same device, peer
+//        copies otherwise); QCD_RING_RCCL: the runs are gathered into one buffer per neighbour, one
+//        ncclSend / ncclRecv per neighbour (one ncclGroup per pass; xGMI between GPUs), and
+//        scattered into the halo slices, all on the lane;
+//     4. the context's stream waits for the halos behind the launch.
+// Measured on a 32^4 slab that is its own neighbour (bare pass 122 us): 130 us per pass with the copy
+// transport, 137 us over RCCL (sends to itself; RCCL's kernel takes 15 us alone and 60 us beside the
+// update launch, whose memory traffic its handshakes queue behind).  Steps on the way (copy transport;
+// over RCCL the first was 191 us): boundary slices and interior as launches on two streams, messages
+// packed into buffers: 150 us -- the kernel of a large range keeps every CU to itself (a workgroup
+// of eight wavefronts and 125 KB of LDS per CU), so the boundary launch ran before it, not beside
+// it, and every hand-over between queues costs 10-20 us; two launches on one stream: 137 us (each
+// launch has its ramp and its tail); one launch with a device-scope release fence per edge block:
+// 149 us (each fence writes back an XCD's whole L2), with write-through stores instead: 128-130 us.
 // RCCL is bound at run time (dlopen), so the library loads on machines without it.
 #include "../../include/qcdgpu_amd.h"
 
@@ -109,13 +123,62 @@ Rccl* rccl()
 struct Part {
     qcd_ctx* ctx = nullptr;
     int device = 0, nx = 0;
-    hipStream_t stream = nullptr;       // the context's stream at the time the ring was made
-    char* out[2] = {nullptr, nullptr};  // message from the first (0) / last (1) owned slice
-    char* in[2] = {nullptr, nullptr};   // message for the left (0) / right (1) halo
-    hipEvent_t packed = nullptr, arrived = nullptr, consumed = nullptr;
-    hipStream_t wire = nullptr;         // RCCL: the stream the part's sends and receives run on
+    hipStream_t stream = nullptr;       // the context's stream: the update launches
+    hipStream_t lane = nullptr;         // beside it: what moves the messages of a pass (copy transport: the copies themselves)
+    // edge_done: the boundary slices are updated (stream, two-launch passes); ready: they can be read
+    // by anyone on the device (lane);
+    // halo_done: both halos are current (lane)
+    hipEvent_t edge_done = nullptr, ready = nullptr, halo_done = nullptr;
     ncclComm_t comm = nullptr;
+    char* out[2] = {nullptr, nullptr};  // RCCL: message from the first (0) / last (1) owned slice, packed
+    char* in[2] = {nullptr, nullptr};   // RCCL: message for the left (0) / right (1) halo
+    // one-launch passes: the update kernel writes the pass's number here when the boundary slices
+    // are done and the lane waits for it (null: the device or this slab cannot, two launches instead)
+    unsigned* signal = nullptr;
+    unsigned signal_seq = 0;
 };
+
+// a message where it lies in a lattice: `pieces` runs of `bytes`, `pitch` apart
+struct Region {
+    char* first = nullptr;
+    size_t bytes = 0, pitch = 0;
+    int pieces = 0;
+};
+
+int region_of(const Part& p, int side, int owned, int dir, int parity, Region& g)
+{
+    void* f = nullptr;
+    const int rc = qcd_halo_region(p.ctx, side, owned, dir, parity, &f, &g.bytes, &g.pitch, &g.pieces);
+    g.first = (char*)f;
+    return rc;
+}
+
+// Up to two messages moved by one launch (blockIdx.y picks the message): the runs of a slice to
+// or from a contiguous buffer, or straight from a boundary slice into a halo slice on the same device.
+struct CopyJob {
+    const double2* src;
+    double2* dst;
+    size_t src_pitch, dst_pitch;   // in elements
+};
+struct CopyJobs {
+    CopyJob job[2];
+};
+__global__ __launch_bounds__(256) void k_slice_copy(const CopyJobs jobs, const int per_piece, const int pieces)
+{
+    const CopyJob j = jobs.job[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_piece * pieces) return;
+    const int c = i / per_piece, r = i - c * per_piece;
+    j.dst[(size_t)c * j.dst_pitch + r] = j.src[(size_t)c * j.src_pitch + r];
+}
+
+int launch_slice_copy(const CopyJobs& jobs, int njobs, const Region& shape, hipStream_t stream)
+{
+    const int per = (int)(shape.bytes / sizeof(double2)), n = per * shape.pieces;
+    hipLaunchKernelGGL(k_slice_copy, dim3((n + 255) / 256, njobs), dim3(256), 0, stream, jobs, per, shape.pieces);
+    RING_HIP(hipGetLastError());
+    return QCD_OK;
+}
 
 }  // namespace
 
@@ -125,22 +188,48 @@ struct qcd_ring {
     int rank0 = 0, world = 1;   // ring position of parts[0] and ring size (world > parts.size(): one part per process)
     size_t bytes = 0;
     unsigned long long passes = 0;
+    unsigned long long signalled = 0;   // part-passes issued as one launch with the edge signal
+    int edge_override = 0;
+    bool one_launch = true;
 };
 
 namespace {
 
 int ring_alloc(qcd_ring* r)
 {
+    if (const char* ov = getenv("QCDGPU_AMD_RING_EDGE")) r->edge_override = atoi(ov);          // diagnostic overrides
+    if (const char* ov = getenv("QCDGPU_AMD_RING_ONE_LAUNCH")) r->one_launch = atoi(ov) != 0;
     for (Part& p : r->parts) {
         RING_HIP(hipSetDevice(p.device));
-        for (int s = 0; s < 2; s++) {
-            RING_HIP(hipMalloc((void**)&p.out[s], r->bytes));
-            RING_HIP(hipMalloc((void**)&p.in[s], r->bytes));
+        RING_HIP(hipEventCreateWithFlags(&p.edge_done, hipEventDisableTiming));
+        RING_HIP(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
+        RING_HIP(hipEventCreateWithFlags(&p.halo_done, hipEventDisableTiming));
+        // ONE stream of ordinary priority beside the context's: gathering, RCCL's sends and receives and
+        // scattering follow one another anyway, and every hand-over between two queues costs 10-15 us.
+        // A process has few hardware queues per device (four by default) and streams beyond that share
+        // them: a stream for RCCL that shared the queue of the context's stream ran RCCL's kernel behind
+        // the update launch instead of beside it.  (Streams of high priority have queues of their own
+        // kind, but the wait for the edge word is a spinning kernel, and on a high-priority queue it kept
+        // the update launch it waits for from starting: the pass hung.)
+        RING_HIP(hipStreamCreateWithFlags(&p.lane, hipStreamNonBlocking));
+        int can_wait = 0;
+        if (r->one_launch && hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, p.device) == hipSuccess && can_wait) {
+            if (hipExtMallocWithFlags((void**)&p.signal, 8, hipMallocSignalMemory) != hipSuccess) {
+                (void)hipGetLastError();
+                p.signal = nullptr;
+            } else {
+                RING_HIP(hipMemset(p.signal, 0, 8));
+            }
         }
-        RING_HIP(hipEventCreateWithFlags(&p.packed, hipEventDisableTiming));
-        RING_HIP(hipEventCreateWithFlags(&p.arrived, hipEventDisableTiming));
-        RING_HIP(hipEventCreateWithFlags(&p.consumed, hipEventDisableTiming));
-        if (r->transport == QCD_RING_RCCL) RING_HIP(hipStreamCreateWithFlags(&p.wire, hipStreamNonBlocking));
+        if (r->transport == QCD_RING_RCCL) {
+            // one send and one receive per neighbour and pass: RCCL moves few large messages much faster
+            // than many small ones (a send per run of a slice, straight out of the lattice: 194 us per pass
+            // of a 32^4 slab against 152 us), so the runs are gathered into a buffer first
+            for (int s = 0; s < 2; s++) {
+                RING_HIP(hipMalloc((void**)&p.out[s], r->bytes));
+                RING_HIP(hipMalloc((void**)&p.in[s], r->bytes));
+            }
+        }
     }
     return QCD_OK;
 }
@@ -167,23 +256,88 @@ int ring_add_parts(qcd_ring* r, qcd_ctx* const* parts, int nparts)
     return QCD_OK;
 }
 
-// steps 1 and 2 of a pass for one part; `heatbath` false: overrelaxation (no split variant)
-int part_update_and_pack(qcd_ring* r, Part& p, int parity, int dir, bool heatbath)
+// How many slices at each face go into the first launch of a pass that takes two.  The first
+// launch holds the messages up, the second hides them: one slice per face is the minimum; for wide
+// parts a few more make the first launch big enough for the kernel that full passes use.
+int edge_slices(const qcd_ring* r, int nx)
+{
+    int a = nx >= 16 ? nx / 8 : 1;
+    if (r->edge_override > 0) a = r->edge_override;
+    if (2 * a > nx) a = nx / 2;
+    return a;
+}
+
+// A pass for one part, as far as it needs nobody else.  On the context's stream: ONE launch that
+// starts with the slices next to the two faces and says when they are done (qcd_update_signal_edges),
+// or, where that is not to be had, two launches, boundary slices first.  On the lane: wait for
+// that moment and record `ready`.  `heatbath` false: overrelaxation (one launch, then `ready`).
+int part_update(qcd_ring* r, Part& p, int parity, int dir, bool heatbath)
 {
     int rc;
     void* st = nullptr;
     if ((rc = qcd_get_stream(p.ctx, &st))) return rc;   // the caller may have given the context another stream since
     p.stream = (hipStream_t)st;
-    if (!heatbath) rc = qcd_overrelax(p.ctx, parity, dir);
-    else if (p.nx >= 4) rc = qcd_update_split(p.ctx, parity, dir, p.nx - 1, 2);   // last and first slice, then the rest beside
-    else rc = qcd_update(p.ctx, parity, dir);
-    if (rc) return rc;
     RING_HIP(hipSetDevice(p.device));
-    // the buffers are free: whoever read the last messages out of them has recorded `consumed`
-    if (r->passes) RING_HIP(hipStreamWaitEvent(p.stream, p.consumed, 0));
-    if ((rc = qcd_halo_pack(p.ctx, 1, dir, parity, p.out[1]))) return rc;
-    if (dir != 0 && (rc = qcd_halo_pack(p.ctx, 0, dir, parity, p.out[0]))) return rc;
-    RING_HIP(hipEventRecord(p.packed, p.stream));
+    const int a = edge_slices(r, p.nx);
+    bool signalled = false;
+    if (heatbath && p.signal && p.nx >= 4) {
+        rc = qcd_update_signal_edges(p.ctx, parity, dir, 1, p.signal, p.signal_seq + 1);
+        if (rc == QCD_OK) {
+            p.signal_seq++;
+            r->signalled++;
+            // passes of a part follow one another (the next launch waits for this pass's halos), so the
+            // word holds this pass's number from the moment it is written until the lane has seen it
+            RING_HIP(hipStreamWaitValue32(p.lane, p.signal, p.signal_seq, hipStreamWaitValueEq, 0xffffffffu));
+            signalled = true;
+        } else if (rc == QCD_ERR_UNSUPPORTED) {
+            RING_HIP(hipFree(p.signal));   // this slab's passes do not run as the kernel that signals
+            p.signal = nullptr;
+        } else {
+            return rc;
+        }
+    }
+    if (!signalled) {
+        if (heatbath && p.nx >= 4 && 2 * a < p.nx) {
+            if ((rc = qcd_update_range(p.ctx, parity, dir, p.nx - a, 2 * a))) return rc;   // wraps: last a and first a slices
+            RING_HIP(hipEventRecord(p.edge_done, p.stream));
+            if ((rc = qcd_update_range(p.ctx, parity, dir, a, p.nx - 2 * a))) return rc;
+        } else {
+            if ((rc = heatbath ? qcd_update(p.ctx, parity, dir) : qcd_overrelax(p.ctx, parity, dir))) return rc;
+            RING_HIP(hipEventRecord(p.edge_done, p.stream));
+        }
+        RING_HIP(hipStreamWaitEvent(p.lane, p.edge_done, 0));
+    }
+    RING_HIP(hipEventRecord(p.ready, p.lane));
+    return QCD_OK;
+}
+
+// copy transport: the halos of `me` from the boundary slices of its neighbours, on me's lane
+int pull(qcd_ring* r, Part& me, Part& left, Part& right, int dir, int parity)
+{
+    // left halo <- left neighbour's last slice; right halo <- right neighbour's first slice (not
+    // for X links: nothing reads U_x one slice to the right)
+    const int njobs = dir != 0 ? 2 : 1;
+    Part* from[2] = {&left, &right};
+    Region src[2], dst[2];
+    int rc;
+    for (int s = 0; s < njobs; s++) {
+        if ((rc = region_of(*from[s], 1 - s, 1, dir, parity, src[s]))) return rc;
+        if ((rc = region_of(me, s, 0, dir, parity, dst[s]))) return rc;
+        if (src[s].bytes != dst[s].bytes || src[s].pieces != dst[s].pieces) return failf(QCD_ERR_INVALID, "parts with different slice shapes");
+        RING_HIP(hipStreamWaitEvent(me.lane, from[s]->ready, 0));
+    }
+    CopyJobs jobs = {};
+    int same = 0;
+    for (int s = 0; s < njobs; s++) {
+        if (from[s]->device == me.device) {
+            jobs.job[same++] = CopyJob{(const double2*)src[s].first, (double2*)dst[s].first, src[s].pitch / sizeof(double2), dst[s].pitch / sizeof(double2)};
+        } else {
+            for (int c = 0; c < src[s].pieces; c++)
+                RING_HIP(hipMemcpyPeerAsync(dst[s].first + c * dst[s].pitch, me.device, src[s].first + c * src[s].pitch, from[s]->device, src[s].bytes,
+                                            me.lane));
+        }
+    }
+    if (same) return launch_slice_copy(jobs, same, src[0], me.lane);
     return QCD_OK;
 }
 
@@ -195,72 +349,66 @@ int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
     const int n = (int)r->parts.size();
     int rc;
     for (Part& p : r->parts)
-        if ((rc = part_update_and_pack(r, p, parity, dir, heatbath))) return rc;
+        if ((rc = part_update(r, p, parity, dir, heatbath))) return rc;
+    // The messages go from lattice to lattice: a boundary slice of the links (dir, parity) is a few
+    // contiguous runs (one per stored matrix element), and so is the halo slice it goes to.  The
+    // pass itself never reads U_dir on sites of this parity, so a halo may be overwritten while the
+    // part's own launch is still running; a boundary slice is not written again before the same
+    // (parity, dir) comes round, eight passes later, and no part gets more than two passes ahead
+    // of a neighbour.
     if (r->transport == QCD_RING_COPY) {
-        // inside one process: the receiver's stream waits for the sender's packing and reads the
-        // sender's buffer -- directly on the same device, through a peer copy otherwise
-        for (int k = 0; k < n; k++) {
-            Part& me = r->parts[k];
-            Part& right = r->parts[(k + 1) % n];
-            Part& left = r->parts[(k + n - 1) % n];
-            RING_HIP(hipSetDevice(me.device));
-            // left halo <- left neighbour's last slice
-            RING_HIP(hipStreamWaitEvent(me.stream, left.packed, 0));
-            const char* src0 = left.out[1];
-            if (left.device != me.device) {
-                RING_HIP(hipMemcpyPeerAsync(me.in[0], me.device, left.out[1], left.device, r->bytes, me.stream));
-                src0 = me.in[0];
-            }
-            if ((rc = qcd_halo_unpack(me.ctx, 0, dir, parity, src0))) return rc;
-            if (dir != 0) {
-                // right halo <- right neighbour's first slice
-                RING_HIP(hipStreamWaitEvent(me.stream, right.packed, 0));
-                const char* src1 = right.out[0];
-                if (right.device != me.device) {
-                    RING_HIP(hipMemcpyPeerAsync(me.in[1], me.device, right.out[0], right.device, r->bytes, me.stream));
-                    src1 = me.in[1];
-                }
-                if ((rc = qcd_halo_unpack(me.ctx, 1, dir, parity, src1))) return rc;
-            }
-            RING_HIP(hipEventRecord(me.arrived, me.stream));
-        }
-        // a part's buffers are free once both neighbours have read them
         for (int k = 0; k < n; k++) {
             Part& me = r->parts[k];
             RING_HIP(hipSetDevice(me.device));
-            RING_HIP(hipStreamWaitEvent(me.stream, r->parts[(k + 1) % n].arrived, 0));
-            RING_HIP(hipStreamWaitEvent(me.stream, r->parts[(k + n - 1) % n].arrived, 0));
-            RING_HIP(hipEventRecord(me.consumed, me.stream));
+            if ((rc = pull(r, me, r->parts[(k + n - 1) % n], r->parts[(k + 1) % n], dir, parity))) return rc;
+            RING_HIP(hipEventRecord(me.halo_done, me.lane));
         }
     } else {
         Rccl* nc = rccl();
+        const int njobs = dir != 0 ? 2 : 1;
         const size_t count = r->bytes / sizeof(double);
         for (Part& p : r->parts) {
+            // gather the runs of the last slice (to the right neighbour) and of the first (to the left)
             RING_HIP(hipSetDevice(p.device));
-            RING_HIP(hipStreamWaitEvent(p.wire, p.packed, 0));
+            Region reg[2];
+            CopyJobs jobs = {};
+            for (int s = 0; s < njobs; s++) {
+                if ((rc = region_of(p, 1 - s, 1, dir, parity, reg[s]))) return rc;
+                jobs.job[s] = CopyJob{(const double2*)reg[s].first, (double2*)p.out[1 - s], reg[s].pitch / sizeof(double2), reg[s].bytes / sizeof(double2)};
+            }
+            if ((rc = launch_slice_copy(jobs, njobs, reg[0], p.lane))) return rc;
         }
         RING_NCCL(nc->GroupStart());
         for (int k = 0; k < n; k++) {
             Part& p = r->parts[k];
             const int me = r->rank0 + k;
             const int right = (me + 1) % r->world, left = (me + r->world - 1) % r->world;
-            RING_NCCL(nc->Send(p.out[1], count, ncclDouble, right, p.comm, p.wire));
-            RING_NCCL(nc->Recv(p.in[0], count, ncclDouble, left, p.comm, p.wire));
+            RING_NCCL(nc->Send(p.out[1], count, ncclDouble, right, p.comm, p.lane));
+            RING_NCCL(nc->Recv(p.in[0], count, ncclDouble, left, p.comm, p.lane));
             if (dir != 0) {
-                RING_NCCL(nc->Send(p.out[0], count, ncclDouble, left, p.comm, p.wire));
-                RING_NCCL(nc->Recv(p.in[1], count, ncclDouble, right, p.comm, p.wire));
+                RING_NCCL(nc->Send(p.out[0], count, ncclDouble, left, p.comm, p.lane));
+                RING_NCCL(nc->Recv(p.in[1], count, ncclDouble, right, p.comm, p.lane));
             }
         }
         RING_NCCL(nc->GroupEnd());
         for (Part& p : r->parts) {
             RING_HIP(hipSetDevice(p.device));
-            RING_HIP(hipEventRecord(p.arrived, p.wire));
-            RING_HIP(hipStreamWaitEvent(p.stream, p.arrived, 0));
-            if ((rc = qcd_halo_unpack(p.ctx, 0, dir, parity, p.in[0]))) return rc;
-            if (dir != 0 && (rc = qcd_halo_unpack(p.ctx, 1, dir, parity, p.in[1]))) return rc;
-            // sends and receives of this pass are done (`arrived`), the incoming buffers are read
-            RING_HIP(hipEventRecord(p.consumed, p.stream));
+            // (the lane gathers the next pass's messages behind this: the outgoing buffers are sent by then)
+            Region reg[2];
+            CopyJobs jobs = {};
+            for (int s = 0; s < njobs; s++) {
+                if ((rc = region_of(p, s, 0, dir, parity, reg[s]))) return rc;
+                jobs.job[s] = CopyJob{(const double2*)p.in[s], (double2*)reg[s].first, reg[s].bytes / sizeof(double2), reg[s].pitch / sizeof(double2)};
+            }
+            if ((rc = launch_slice_copy(jobs, njobs, reg[0], p.lane))) return rc;
+            RING_HIP(hipEventRecord(p.halo_done, p.lane));
         }
+    }
+    // whatever comes next on a context's stream -- the next pass, a measurement -- finds the halos
+    // current
+    for (Part& p : r->parts) {
+        RING_HIP(hipSetDevice(p.device));
+        RING_HIP(hipStreamWaitEvent(p.stream, p.halo_done, 0));
     }
     r->passes++;
     return QCD_OK;
@@ -352,16 +500,17 @@ void qcd_ring_destroy(qcd_ring* r)
     for (Part& p : r->parts) {
         (void)hipSetDevice(p.device);
         if (p.stream) (void)hipStreamSynchronize(p.stream);
-        if (p.wire) (void)hipStreamSynchronize(p.wire);
+        if (p.lane) (void)hipStreamSynchronize(p.lane);
         if (p.comm && rccl()->lib) (void)rccl()->CommDestroy(p.comm);
+        if (p.edge_done) (void)hipEventDestroy(p.edge_done);
+        if (p.ready) (void)hipEventDestroy(p.ready);
         for (int s = 0; s < 2; s++) {
             (void)hipFree(p.out[s]);
             (void)hipFree(p.in[s]);
         }
-        if (p.packed) (void)hipEventDestroy(p.packed);
-        if (p.arrived) (void)hipEventDestroy(p.arrived);
-        if (p.consumed) (void)hipEventDestroy(p.consumed);
-        if (p.wire) (void)hipStreamDestroy(p.wire);
+        if (p.halo_done) (void)hipEventDestroy(p.halo_done);
+        if (p.lane) (void)hipStreamDestroy(p.lane);
+        if (p.signal) (void)hipFree(p.signal);
     }
     delete r;
 }
@@ -399,6 +548,13 @@ int qcd_ring_fill_halos(qcd_ring* r)
                 return failf(QCD_ERR_UNSUPPORTED, "halo fill over RCCL: start cold or gid, or fill with the copy transport");
             }
         }
+    return QCD_OK;
+}
+
+int qcd_ring_one_launch_passes(qcd_ring* r, unsigned long long* n)
+{
+    if (!r || !n) return failf(QCD_ERR_INVALID, "null argument");
+    *n = r->signalled;
     return QCD_OK;
 }
 

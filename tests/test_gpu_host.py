@@ -465,6 +465,72 @@ def test_ring_pass_below_the_c_abi_equals_uncut_lattice(group, L, parts, beta, n
         lat.close()
 
 
+@pytest.mark.parametrize("transport", ["copy", "rccl"])
+def test_ring_one_launch_pass_32_against_checker_fixture(transport):
+    """A 32^4 slab that is its own neighbour on both sides: every pass goes out as ONE launch that
+    takes the boundary slices first and signals from inside the kernel when they are in memory, the
+    messages travel beside the rest of the launch.  Two sweeps against the CPU checker's numbers for
+    the periodic 32^4 lattice (plaquette 1e-12, equal count of random numbers)."""
+    import json
+    import qcdgpu_amd as q
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "persite_su3_32x32x32x32_b6.json")))
+    L = (32, 32, 32, 32)
+    c = q.Context(group=3, L=L, beta=6.0, nhit=10, rand_series=54, x0=0, nx_local=32, halo=1)
+    c.init_lattice()
+    ring = q.Ring([c], q.RING_COPY if transport == "copy" else q.RING_RCCL)
+    try:
+        for row in fx["sweeps"]:
+            ring.sweep(1)
+            sums = c.plaquette_sums()
+            v = float(np.prod(L))
+            got = np.array([sums[0] / (3 * v), sums[1] / (3 * v), (sums[0] + sums[1]) / (6 * v)])
+            assert np.max(np.abs(got - row["plaquette"]) / np.abs(row["plaquette"])) < 1e-12
+            assert c.rng_draws() == row["rng_draws"]
+        assert ring.one_launch_passes() == 8 * len(fx["sweeps"])
+    finally:
+        ring.close()
+        c.close()
+
+
+def test_ring_one_launch_passes_two_parts_equal_uncut_lattice(monkeypatch):
+    """Two slabs of 8 slices of a 16 x 32^3 lattice on the one device, passes as one launch with
+    the in-kernel edge signal, against the uncut lattice in one context: same sums and draw counts
+    after every sweep, same links at the end; and the same again with the signal switched off
+    (two launches per pass, boundary slices first)."""
+    import qcdgpu_amd as q
+    L = (16, 32, 32, 32)
+    kw = dict(group=3, L=L, beta=5.9, nhit=6, rand_series=77)
+    one = q.Context(**kw)
+    one.init_lattice()
+    want = []
+    for s in range(2):
+        one.sweep(1)
+        want.append((one.plaquette_sums(), one.polyakov_sums(), one.rng_draws()))
+    want_links = one.download()
+    one.close()
+    for signal in (True, False):
+        monkeypatch.setenv("QCDGPU_AMD_RING_ONE_LAUNCH", "1" if signal else "0")
+        ctxs = [q.Context(x0=8 * k, nx_local=8, halo=1, **kw) for k in range(2)]
+        for c in ctxs:
+            c.init_lattice()
+        ring = q.Ring(ctxs, q.RING_COPY)
+        try:
+            for s in range(2):
+                ring.sweep(1)
+                plq = np.sum([c.plaquette_sums() for c in ctxs], axis=0)
+                pol = np.sum([c.polyakov_sums() for c in ctxs], axis=0)
+                assert np.allclose(plq, want[s][0], rtol=1e-13)
+                assert np.allclose(pol, want[s][1], rtol=1e-12, atol=1e-9)
+                assert sum(c.rng_draws() for c in ctxs) == want[s][2]
+            assert ring.one_launch_passes() == (32 if signal else 0)
+            got = np.concatenate([c.download() for c in ctxs], axis=1)
+            assert np.max(np.abs(got - want_links)) < 1e-11
+        finally:
+            ring.close()
+            for c in ctxs:
+                c.close()
+
+
 @pytest.mark.parametrize("by_rank", [False, True])
 def test_ring_over_rccl_on_one_gpu(by_rank):
     """The RCCL transport where a one-GPU box can run it: a ring of ONE part whose neighbours on

@@ -61,3 +61,28 @@ for _ in range(5):
     best = min(best, time.perf_counter() - t0)
 torch.cuda.synchronize()
 print("Python    : into empty queues the host issues a pass of one part in %5.1f us" % (1e6 * best / 16))
+for e in big.engines:
+    e.ctx.close()
+
+# one 32^4 slab whose neighbours on both sides are itself: bare pass, copy transport, RCCL transport
+# (what a rank of an N-GPU run does per pass, minus the link between two devices)
+def slab_pass_us(transport):
+    c = q.Context(group=3, L=L, beta=6.0, x0=0, nx_local=32, halo=1) if transport is not None else q.Context(group=3, L=L, beta=6.0)
+    c.init_lattice()
+    r = q.Ring([c], transport) if transport is not None else None
+    run = r.sweep if r is not None else c.sweep
+    run(3)
+    c.synchronize() if r is None else r.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run(n)
+        c.synchronize() if r is None else r.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    if r is not None:
+        print("   (%s: %d of %d passes as one launch with the edge signal)" % ("RCCL" if transport == q.RING_RCCL else "copy", r.one_launch_passes(), 8 * (3 + 3 * n)))
+        r.close()
+    c.close()
+    return 1e6 * best / (8 * n)
+print("32^4 slab, halo of one slice, per pass: bare update %6.1f us, ring with copy transport %6.1f us, ring over RCCL (sends to itself) %6.1f us"
+      % (slab_pass_us(None), slab_pass_us(q.RING_COPY), slab_pass_us(q.RING_RCCL)), flush=True)
