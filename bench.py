@@ -169,6 +169,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    p2p_group = None
     n = args.L
     L = (n * world, n, n, n)
     sites_per_gpu = n ** 4
@@ -181,10 +182,32 @@ def main():
         plaquette = ctx.plaquette
         sync = ctx.synchronize
     else:
+        lat = None
         if transport == "ring":
-            lat = bl.make_rank_ring(3, L, args.beta, rank, world, local_rank, **kw)
-        else:
-            lat = bl.make_rank_slab(3, L, args.beta, rank, world, local_rank, **kw)
+            # every rank must end up on the same transport: agree on whether the ring came up everywhere
+            try:
+                lat = bl.make_rank_ring(3, L, args.beta, rank, world, local_rank, **kw)
+                problem = None
+            except Exception as e:  # noqa: BLE001
+                problem = e
+            ok = torch.tensor([0 if problem is not None else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if problem is not None:
+                    print("[bench] rank %d: no RCCL ring (%s)" % (rank, problem), file=sys.stderr, flush=True)
+                log("the C library's RCCL ring did not come up on every rank: halos over torch.distributed P2P (RCCL) instead")
+                if lat is not None:
+                    lat.close()
+                    lat.ctx.close()
+                lat = None
+                transport = "torch"
+                if os.environ.get("QCDGPU_BENCH_BACKEND") == "gloo":   # rehearsal on one GPU: staged through the host
+                    backend = "gloo"
+                else:
+                    p2p_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                    backend = "nccl (second process group)"
+        if lat is None:
+            lat = bl.make_rank_slab(3, L, args.beta, rank, world, local_rank, dist_group=p2p_group, **kw)
         ctx = lat.engines[0].ctx
         sweep = lat.sweep
         plaquette = lat.plaquette
@@ -288,7 +311,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS,
                      # PMC traffic was collected on this workload (32^4 SU(3) per GPU) only
                      "traffic": measured_traffic() if (n == 32 and args.beta == 6.0) else None,
-                     "kernel": "k_update", "launches": int(launches),
+                     "kernel": "k_update_gh" if (world == 1 and n >= 16) else "k_update_gh / k_update", "launches": int(launches),
                      "avg_launch_us": 1e6 * per_launch_s,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }

@@ -94,3 +94,23 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert doc["value"] > 0 and doc["roofline"]["launches"] >= 16
     # 5 sweeps of 32 x 16^3 from a cold start at beta = 6: the plaquette has left 3 and is still above its equilibrium value
     assert 1.7 < doc["mean_plaquette"]["Plq_total"] < 2.2
+
+
+def test_bench_falls_back_when_the_rccl_ring_does_not_come_up(tmp_path):
+    """Two ranks told to use the C library's RCCL ring on ONE device: RCCL refuses two ranks on a
+    device, every rank reports that, the ranks agree (over gloo) and the run goes on with the Python
+    driver's exchange -- the same plaquette as the run that used that exchange from the start."""
+    docs = []
+    for transport in ("ring", "torch"):
+        env = dict(os.environ, QCDGPU_BENCH_SHARE_DEVICE="1", QCDGPU_BENCH_BACKEND="gloo", QCDGPU_BENCH_TRANSPORT=transport,
+                   OMP_NUM_THREADS="1")
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                            "--brackets", "1", "--L", "8", "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        if transport == "ring":
+            assert "did not come up on every rank" in r.stderr
+        docs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    assert "torch.distributed" in docs[0]["config"]["halo_transport"]
+    assert docs[0]["mean_plaquette"]["Plq_total"] == docs[1]["mean_plaquette"]["Plq_total"]
