@@ -647,6 +647,37 @@ __device__ __forceinline__ void pin(rows2& m)
                       "+v"(m.e[1][1].re), "+v"(m.e[1][1].im), "+v"(m.e[1][2].re), "+v"(m.e[1][2].im)
                  :: "memory");
 }
+// Cache policy of the staple's requests.  A non-temporal load tells the L2 that its lines will not be
+// asked for again, and the L2 acts on it: with the hint on all 19 requests of a link update a 32^4 pass
+// takes 185 us instead of 118.  A link is asked for by up to six sites of a pass, so the hint belongs on the
+// request that comes last, and only there.  Measured one request at a time (tools/abl_dirs.sh):
+//   U_nu(x-nu)    the closing link of a backward term; the line was first asked for as U_nu(x'+mu) by
+//                 x' = x-nu-mu, one term earlier in the pipeline of a block that runs earlier or beside
+//                 this one: hint on, -3.0 us per pass
+//   U_mu(x)       the link that is updated is read once: hint on, -1.6 us
+//   U_nu(x), U_nu(x-nu+mu)  the same line for x and x' = x+nu-mu; which of the two comes later depends on
+//                 how the blocks run: hint on either costs 1.5-5 us
+//   U_mu(x+-nu)   six requests per line from up to five blocks: no request is reliably the last (+-0.5 us)
+// (SU(2), whose lattice stays in the memory-side cache: the hint on U_nu(x-nu) makes a 32^4 pass 2 us slower.)
+// One mask per direction mu: bit 3 * which + k asks for the non-temporal policy on request `which` of the
+// k-th direction nu != mu (which: 0 = U_nu(x+mu), 1 = U_mu(x+nu), 2 = U_nu(x), 3 = U_mu(x-nu),
+// 4 = U_nu(x-nu+mu), 5 = U_nu(x-nu)); bit 18: the link that is updated.
+#ifndef QCD_NT_D0
+#define QCD_NT_D0 0x78000
+#define QCD_NT_D1 0x78000
+#define QCD_NT_D2 0x78000
+#define QCD_NT_D3 0x78000
+#endif
+constexpr int AUX_NT = 2;
+__host__ __device__ constexpr unsigned nt_mask(int mu)
+{
+    return mu == 0 ? (QCD_NT_D0) : (mu == 1 ? (QCD_NT_D1) : (mu == 2 ? (QCD_NT_D2) : (QCD_NT_D3)));
+}
+__host__ __device__ constexpr int staple_aux(int mu, int nu, int which)
+{
+    const int k = nu < mu ? nu : nu - 1;
+    return ((nt_mask(mu) >> (3 * which + k)) & 1u) ? AUX_NT : ((which == 1 || which == 3) ? 0 : QCD_NU_AUX);
+}
 template <int DIR, int TERM>
 __device__ __forceinline__ raw_pair issue_ab(const double2* __restrict__ U, const Geom& g, const int hb,
                                              const NbrOff& n, const int par)
@@ -656,12 +687,12 @@ __device__ __forceinline__ raw_pair issue_ab(const double2* __restrict__ U, cons
     const int fmu = off_fwd(n, DIR);
     raw_pair t;
     if (TERM % 2 == 0) {
-        t.a = issue_link<QCD_NU_AUX>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + fmu);
-        t.b = issue_link(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + off_fwd(n, nu));
+        t.a = issue_link<staple_aux(DIR, nu, 0)>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + fmu);
+        t.b = issue_link<staple_aux(DIR, nu, 1)>(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + off_fwd(n, nu));
     } else {
         const int bnu = off_bwd(n, nu);
-        t.a = issue_link(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + bnu);
-        t.b = issue_link<QCD_NU_AUX>(link_rsrc<3>(U, g, nu, par), g, hb + bnu + fmu);
+        t.a = issue_link<staple_aux(DIR, nu, 3)>(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + bnu);
+        t.b = issue_link<staple_aux(DIR, nu, 4)>(link_rsrc<3>(U, g, nu, par), g, hb + bnu + fmu);
     }
     return t;
 }
@@ -671,8 +702,8 @@ __device__ __forceinline__ raw_link issue_c(const double2* __restrict__ U, const
 {
     constexpr int k = TERM / 2;
     constexpr int nu = (k < DIR) ? k : k + 1;
-    if (TERM % 2 == 0) return issue_link<QCD_NU_AUX>(link_rsrc<3>(U, g, nu, par), g, hb);
-    return issue_link<QCD_NU_AUX>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_bwd(n, nu));
+    if (TERM % 2 == 0) return issue_link<staple_aux(DIR, nu, 2)>(link_rsrc<3>(U, g, nu, par), g, hb);
+    return issue_link<staple_aux(DIR, nu, 5)>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_bwd(n, nu));
 }
 // first product of a term: two rows of a * b^+ (forward) or of a * b (backward)
 template <int TERM>
@@ -941,7 +972,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             raw_link own;
             RlxRegs r;
             staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, NoHook());
-            own = issue_link(r_own, g, hb);
+            own = issue_link<(((nt_mask(DIR) >> 18) & 1u) ? AUX_NT : 0)>(r_own, g, hb);
             if (!GID) rs.fetch(r);
             A = sp.stap;
             QCD_STAMP(1);
@@ -1192,7 +1223,7 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
             RlxFast<64, NSKIP> rs;
             rs.attach(a.rv, cur.stream, rcol);
             RlxRegs r;
-            raw_link own = issue_link(r_own, g, cur.hb);
+            raw_link own = issue_link<(((nt_mask(DIR) >> 18) & 1u) ? AUX_NT : 0)>(r_own, g, cur.hb);
             rs.fetch(r);
             rs.generate(r);
             const int s = it % GH_SLOTS;

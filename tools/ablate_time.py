@@ -9,11 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CODE = r'''
 import sys; sys.path.insert(0, %r)
 import qcdgpu_amd as q
-c = q.Context(group=3, L=(32,32,32,32), beta=6.0); c.init_lattice(); c.sweep(3)
-best = 1e9
-for _ in range(3):
-    ms, n = c.timed_sweeps(5); best = min(best, ms / n)
-print("%%8.1f us/launch  %%6.2f Gupd/s" %% (1e3 * best, 524288 / best / 1e6))
+c = q.Context(group=3, L=(32,32,32,32), beta=6.0); c.init_lattice(); c.sweep(20)
+ts = []
+for _ in range(7):
+    ms, n = c.timed_sweeps(20); ts.append(1e3 * ms / n)
+ts.sort()
+print("min %%6.1f  median %%6.1f  max %%6.1f us/launch  %%6.2f Gupd/s" %% (ts[0], ts[3], ts[-1], 524288 / ts[3] / 1e3))
 ''' % ROOT
 for lib in sorted(glob.glob(os.path.join(ROOT, "qcdgpu_amd", "lib", "abl", "*.so"))):
     env = dict(os.environ, QCDGPU_AMD_LIB=lib)
