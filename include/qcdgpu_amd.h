@@ -43,7 +43,8 @@ typedef struct {
     int      group;        /* lattice_group: 2 or 3 */
     int      nd;           /* lattice_nd: 4 */
     int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (all even: QCD_ERR_UNSUPPORTED otherwise) */
-    int      precision;    /* 2 = double (model_precision_double); others unsupported */
+    int      precision;    /* 2 = double, 1 = single, 3 = mixed (model::convert_precision_to_uint,
+                              SU(N)/suncl/suncl.cpp:732-737); must be what qcd_precision() reports (3 counts as 1) */
     double   beta;         /* BETA */
     int      nhit;         /* NHIT: max heat-bath trials per SU(2) subgroup */
     int      start_mode;   /* QCD_START_* (INTS) */
@@ -72,6 +73,14 @@ void qcd_destroy(qcd_ctx *ctx);
 
 /* message of the last failing call on this thread */
 const char *qcd_last_error(void);
+
+/* The precision this library was built for: 2 = double (libqcdgpu_amd.so), 1 = single
+ * (libqcdgpu_amd_f32.so: links, staples and the heat-bath in float, lattice sums in double).  The reference
+ * fixes the precision when it builds its kernels (-D PRECISION, SU(N)/suncl/suncl.cpp:3274-3301,
+ * SU(N)/kernel/complex.h:57-92) and sets it in its source, SU(N)/QCDGPU.cpp:178-179; here it is the
+ * choice of the library a program loads.  Both libraries export the same entry points; link tables
+ * (qcd_upload/qcd_download, the halo messages) are in the library's precision. */
+int qcd_precision(void);
 
 /* use a caller-owned hipStream_t (passed as void*) for all subsequent work; NULL is the device's
  * default stream.  qcd_reset_stream goes back to the context's own (non-blocking) stream. */

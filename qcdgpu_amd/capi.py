@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QCDGPU_AMD_LIB") or os.path.join(_HERE, "lib", "libqcdgpu_amd.so")
+# the same entry points built for single precision (qcd_precision() = 1)
+LIB_F32_PATH = os.environ.get("QCDGPU_AMD_LIB_F32") or os.path.join(_HERE, "lib", "libqcdgpu_amd_f32.so")
 
 START_HOT, START_COLD, START_GID = 0, 1, 2
 
@@ -41,7 +43,7 @@ class Timing(C.Structure):
 
 
 # every symbol include/qcdgpu_amd.h declares
-EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd_reset_stream",
+EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_precision", "qcd_set_stream", "qcd_reset_stream",
            "qcd_synchronize",
            "qcd_init_lattice", "qcd_update", "qcd_sweep", "qcd_reunitarize",
            "qcd_measure_plaquette", "qcd_measure_action", "qcd_measure_polyakov",
@@ -59,7 +61,8 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_set_stream", "qcd
            "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize", "qcd_ring_one_launch_passes"]
 
 
-def _load():
+def _load(path=None):
+    path = path or LIB_PATH
     # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  A process must end up with ONE copy:
     # when torch is importable it is imported first, so that this library binds to the runtime
     # torch has already loaded (torch initialised after a second runtime sees no GPUs).
@@ -68,10 +71,10 @@ def _load():
             import torch  # noqa: F401
         except ImportError:
             pass
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; "
-                          "g.build()'` (hipcc --offload-arch=gfx950)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                          "g.build()'` (hipcc --offload-arch=gfx950)" % path)
+    lib = C.CDLL(path)
     P, I, D = C.c_void_p, C.c_int, C.c_double
     pd = C.POINTER(C.c_double)
     lib.qcd_create.argtypes = [C.POINTER(P), C.POINTER(Params)]
@@ -153,11 +156,20 @@ def _load():
 
 
 lib = _load()
+_lib_f32 = None
 
 
-def _check(rc):
+def lib_f32():
+    """The single-precision build of the library, loaded on first use."""
+    global _lib_f32
+    if _lib_f32 is None:
+        _lib_f32 = _load(LIB_F32_PATH)
+    return _lib_f32
+
+
+def _check(rc, l=None):
     if rc != 0:
-        raise QcdError(rc, lib.qcd_last_error().decode())
+        raise QcdError(rc, (l or lib).qcd_last_error().decode())
 
 
 class Context:
@@ -177,12 +189,18 @@ class Context:
         self.group = group
         self.sites = int(np.prod(L))
         self.local_sites = p.nx_local * L[1] * L[2] * L[3]
+        # precision 2 = double: libqcdgpu_amd.so; 1 = single, 3 = mixed: libqcdgpu_amd_f32.so
+        self.lib = lib if precision == 2 else lib_f32()
+        self.dtype = np.float64 if precision == 2 else np.float32
         self.h = C.c_void_p()
-        _check(lib.qcd_create(C.byref(self.h), C.byref(p)))
+        self._check(self.lib.qcd_create(C.byref(self.h), C.byref(p)))
+
+    def _check(self, rc):
+        _check(rc, self.lib)
 
     def close(self):
         if getattr(self, "h", None):
-            lib.qcd_destroy(self.h)
+            self.lib.qcd_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -195,105 +213,105 @@ class Context:
         self.close()
 
     def set_stream(self, stream_handle):
-        _check(lib.qcd_set_stream(self.h, C.c_void_p(stream_handle)))
+        self._check(self.lib.qcd_set_stream(self.h, C.c_void_p(stream_handle)))
 
     def synchronize(self):
-        _check(lib.qcd_synchronize(self.h))
+        self._check(self.lib.qcd_synchronize(self.h))
 
     def init_lattice(self):
-        _check(lib.qcd_init_lattice(self.h))
+        self._check(self.lib.qcd_init_lattice(self.h))
 
     def update(self, parity, direction):
-        _check(lib.qcd_update(self.h, parity, direction))
+        self._check(self.lib.qcd_update(self.h, parity, direction))
 
     def sweep(self, n=1):
-        _check(lib.qcd_sweep(self.h, n))
+        self._check(self.lib.qcd_sweep(self.h, n))
 
     def reunitarize(self):
-        _check(lib.qcd_reunitarize(self.h))
+        self._check(self.lib.qcd_reunitarize(self.h))
 
     def _measure(self, fn, n):
         out = (C.c_double * n)()
-        _check(fn(self.h, out))
+        self._check(fn(self.h, out))
         return np.array(out[:])
 
     def plaquette(self):
-        return self._measure(lib.qcd_measure_plaquette, 3)
+        return self._measure(self.lib.qcd_measure_plaquette, 3)
 
     def action(self):
-        return self._measure(lib.qcd_measure_action, 3)
+        return self._measure(self.lib.qcd_measure_action, 3)
 
     def polyakov(self):
-        return self._measure(lib.qcd_measure_polyakov, 4)
+        return self._measure(self.lib.qcd_measure_polyakov, 4)
 
     def plaquette_sums(self):
-        return self._measure(lib.qcd_measure_plaquette_sums, 2)
+        return self._measure(self.lib.qcd_measure_plaquette_sums, 2)
 
     def plaquette_sums_static(self, dev_ptr):
         """(sum_spat, sum_temp) into two doubles of device memory at dev_ptr, asynchronously, without
         any allocation (the entry point for callers that cannot allocate)."""
-        _check(lib.qcd_measure_plaquette_sums_static(self.h, C.c_void_p(dev_ptr)))
+        self._check(self.lib.qcd_measure_plaquette_sums_static(self.h, C.c_void_p(dev_ptr)))
 
     def polyakov_sums(self):
-        return self._measure(lib.qcd_measure_polyakov_sums, 4)
+        return self._measure(self.lib.qcd_measure_polyakov_sums, 4)
 
     def rows(self):
         return 12 if self.group == 3 else 4
 
     def upload(self, table):
-        t = np.ascontiguousarray(table, dtype=np.float64)
+        t = np.ascontiguousarray(table, dtype=self.dtype)
         assert t.ndim == 3 and t.shape[0] == self.rows() and t.shape[2] == 4
-        _check(lib.qcd_upload(self.h, t.ctypes.data_as(C.c_void_p), t.nbytes, t.shape[1]))
+        self._check(self.lib.qcd_upload(self.h, t.ctypes.data_as(C.c_void_p), t.nbytes, t.shape[1]))
 
     def download(self, rowsize=None):
         rowsize = rowsize or self.local_sites
-        t = np.zeros((self.rows(), rowsize, 4), dtype=np.float64)
-        _check(lib.qcd_download(self.h, t.ctypes.data_as(C.c_void_p), t.nbytes, rowsize))
+        t = np.zeros((self.rows(), rowsize, 4), dtype=self.dtype)
+        self._check(self.lib.qcd_download(self.h, t.ctypes.data_as(C.c_void_p), t.nbytes, rowsize))
         return t
 
     def halo_bytes(self):
-        return lib.qcd_halo_bytes(self.h)
+        return self.lib.qcd_halo_bytes(self.h)
 
     def halo_pack(self, side, direction, parity, dev_ptr):
-        _check(lib.qcd_halo_pack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
+        self._check(self.lib.qcd_halo_pack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
 
     def halo_unpack(self, side, direction, parity, dev_ptr):
-        _check(lib.qcd_halo_unpack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
+        self._check(self.lib.qcd_halo_unpack(self.h, side, direction, parity, C.c_void_p(dev_ptr)))
 
     def halo_copy_to(self, pack_side, dst, recv_side, direction, parity):
-        _check(lib.qcd_halo_copy(self.h, pack_side, dst.h, recv_side, direction, parity))
+        self._check(self.lib.qcd_halo_copy(self.h, pack_side, dst.h, recv_side, direction, parity))
 
     def set_profiling(self, on):
-        _check(lib.qcd_set_profiling(self.h, int(on)))
+        self._check(self.lib.qcd_set_profiling(self.h, int(on)))
 
     def timing(self):
         t = Timing()
-        _check(lib.qcd_get_timing(self.h, C.byref(t)))
+        self._check(self.lib.qcd_get_timing(self.h, C.byref(t)))
         return t
 
     def timed_sweeps(self, n):
         ms = C.c_double()
         launches = C.c_ulonglong()
-        _check(lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
+        self._check(self.lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
         return ms.value, launches.value
 
     def update_range(self, parity, direction, xs_begin, xs_count):
-        _check(lib.qcd_update_range(self.h, parity, direction, xs_begin, xs_count))
+        self._check(self.lib.qcd_update_range(self.h, parity, direction, xs_begin, xs_count))
 
     def update_split(self, parity, direction, first_begin, first_count):
         """One pass: slices [first_begin, +first_count) on the context's stream, the rest beside them."""
-        _check(lib.qcd_update_split(self.h, parity, direction, first_begin, first_count))
+        self._check(self.lib.qcd_update_split(self.h, parity, direction, first_begin, first_count))
 
     def wilson_loop(self, R, T):
         out = C.c_double()
-        _check(lib.qcd_measure_wilson(self.h, R, T, C.byref(out)))
+        self._check(self.lib.qcd_measure_wilson(self.h, R, T, C.byref(out)))
         return out.value
 
     def fmunu(self, field, index1=3, index2=8, sums=False):
         """F_mu_nu traces: for (index1, index2) x three planes x (re, im); field 0 = xy,xz,yz, 1 = xt,yt,zt."""
         out = (C.c_double * 12)()
-        fn = lib.qcd_measure_fmunu_sums if sums else lib.qcd_measure_fmunu
-        _check(fn(self.h, field, index1, index2, out))
+        fn = self.lib.qcd_measure_fmunu_sums if sums else self.lib.qcd_measure_fmunu
+        self._check(fn(self.h, field, index1, index2, out))
         return np.array(out[:])
 
     def _profile_extent(self, axis):
@@ -303,36 +321,36 @@ class Context:
         """Raw (spat, temp) ReTr plaquette sums of the owned sites per coordinate along axis (0 x, 1 y, 2 z)."""
         n = self._profile_extent(axis)
         out = (C.c_double * (2 * n))()
-        _check(lib.qcd_measure_plaquette_profile_sums(self.h, axis, out))
+        self._check(self.lib.qcd_measure_plaquette_profile_sums(self.h, axis, out))
         return np.array(out[:]).reshape(n, 2)
 
     def polyakov_profile_sums(self, axis):
         """Raw (Re P, Im P) Polyakov-loop sums per coordinate along axis (0 x, 1 y, 2 z)."""
         n = self._profile_extent(axis)
         out = (C.c_double * (2 * n))()
-        _check(lib.qcd_measure_polyakov_profile_sums(self.h, axis, out))
+        self._check(self.lib.qcd_measure_polyakov_profile_sums(self.h, axis, out))
         return np.array(out[:]).reshape(n, 2)
 
     def overrelax(self, parity, direction):
-        _check(lib.qcd_overrelax(self.h, parity, direction))
+        self._check(self.lib.qcd_overrelax(self.h, parity, direction))
 
     def overrelax_sweep(self, n=1):
-        _check(lib.qcd_overrelax_sweep(self.h, n))
+        self._check(self.lib.qcd_overrelax_sweep(self.h, n))
 
     def rng_state(self):
         """The RANLUX streams' state as bytes (for checkpoints)."""
-        n = lib.qcd_rng_state_bytes(self.h)
+        n = self.lib.qcd_rng_state_bytes(self.h)
         buf = np.empty(n, dtype=np.uint8)
-        _check(lib.qcd_rng_state_download(self.h, buf.ctypes.data_as(C.c_void_p), n))
+        self._check(self.lib.qcd_rng_state_download(self.h, buf.ctypes.data_as(C.c_void_p), n))
         return buf
 
     def set_rng_state(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        _check(lib.qcd_rng_state_upload(self.h, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
+        self._check(self.lib.qcd_rng_state_upload(self.h, buf.ctypes.data_as(C.c_void_p), buf.nbytes))
 
     def rng_draws(self):
         d = C.c_ulonglong()
-        _check(lib.qcd_rng_draws(self.h, C.byref(d)))
+        self._check(self.lib.qcd_rng_draws(self.h, C.byref(d)))
         return d.value
 
 
@@ -344,13 +362,14 @@ class Ring:
 
     def __init__(self, contexts, transport=RING_COPY, rank=None, world=None, unique_id=None):
         self.contexts = list(contexts)
+        self.lib = self.contexts[0].lib   # the library (precision) of the ring's contexts
         self.h = C.c_void_p()
         if rank is None:
             arr = (C.c_void_p * len(self.contexts))(*[c.h for c in self.contexts])
-            _check(lib.qcd_ring_create(C.byref(self.h), arr, len(self.contexts), transport))
+            _check(self.lib.qcd_ring_create(C.byref(self.h), arr, len(self.contexts), transport), self.lib)
         else:
             buf = (C.c_char * 128).from_buffer_copy(unique_id)
-            _check(lib.qcd_ring_create_rank(C.byref(self.h), self.contexts[0].h, rank, world, buf, 128))
+            _check(self.lib.qcd_ring_create_rank(C.byref(self.h), self.contexts[0].h, rank, world, buf, 128), self.lib)
 
     @staticmethod
     def unique_id():
@@ -360,31 +379,31 @@ class Ring:
 
     def close(self):
         if getattr(self, "h", None):
-            lib.qcd_ring_destroy(self.h)
+            self.lib.qcd_ring_destroy(self.h)
             self.h = None
 
     def __del__(self):
         self.close()
 
     def update(self, parity, direction):
-        _check(lib.qcd_ring_update(self.h, parity, direction))
+        _check(self.lib.qcd_ring_update(self.h, parity, direction), self.lib)
 
     def overrelax(self, parity, direction):
-        _check(lib.qcd_ring_overrelax(self.h, parity, direction))
+        _check(self.lib.qcd_ring_overrelax(self.h, parity, direction), self.lib)
 
     def sweep(self, n=1):
-        _check(lib.qcd_ring_sweep(self.h, n))
+        _check(self.lib.qcd_ring_sweep(self.h, n), self.lib)
 
     def fill_halos(self):
-        _check(lib.qcd_ring_fill_halos(self.h))
+        _check(self.lib.qcd_ring_fill_halos(self.h), self.lib)
 
     def synchronize(self):
-        _check(lib.qcd_ring_synchronize(self.h))
+        _check(self.lib.qcd_ring_synchronize(self.h), self.lib)
 
     def one_launch_passes(self):
         """Passes of parts issued as one launch with the in-kernel edge signal so far."""
         n = C.c_ulonglong(0)
-        _check(lib.qcd_ring_one_launch_passes(self.h, C.byref(n)))
+        _check(self.lib.qcd_ring_one_launch_passes(self.h, C.byref(n)), self.lib)
         return int(n.value)
 
 

@@ -92,7 +92,7 @@ int fail_msg(int code, const char* msg)
 
 struct qcd_ctx {
     qcd_params p;
-    double2* edge_buf;        // message buffer of qcd_halo_copy (lazily allocated)
+    real2* edge_buf;          // message buffer of qcd_halo_copy (lazily allocated)
     hipEvent_t edge_ev;
     Geom g;
     int ncomp;
@@ -104,7 +104,7 @@ struct qcd_ctx {
     unsigned* edge_count = nullptr;
     int gh_mode;              // 0 never, 1 when the launch has at least 8 * gh_grid blocks, 2 whenever possible
     hipStream_t own_stream, stream;
-    double2* U;
+    real2* U;
     size_t U_elems;
     RlxView rv;
     unsigned char* slice_slot;   // per owned x-slice: the slot its streams' states are in (see RlxView::cur)
@@ -354,7 +354,7 @@ void gid_link(int group, int gid, int dir, int sites, double q[12])
     }
 }
 
-int convert_slices(qcd_ctx* c, double4* dev_table, int rowsize, int slice0, int nslices, bool to_engine)
+int convert_slices(qcd_ctx* c, real4* dev_table, int rowsize, int slice0, int nslices, bool to_engine)
 {
     const int n = nslices * c->g.gslice;
     const dim3 grid(cdiv(n, MEAS_BLOCK)), block(MEAS_BLOCK);
@@ -376,7 +376,7 @@ int upload_gid_slices(qcd_ctx* c, int gx0, int slice0, int nslices)
     const int rows = (c->p.group == 3) ? 12 : 4;
     const int quads = rows / 4;
     const int n = nslices * g.gslice;
-    std::vector<double> tab((size_t)rows * n * 4);
+    std::vector<real> tab((size_t)rows * n * 4);
     for (int xl = 0; xl < nslices; xl++) {
         const int gx = ((gx0 + xl) % c->p.L[0] + c->p.L[0]) % c->p.L[0];
         for (int r = 0; r < g.gslice; r++) {
@@ -386,13 +386,13 @@ int upload_gid_slices(qcd_ctx* c, int gx0, int slice0, int nslices)
                 double q[12];
                 gid_link(c->p.group, gid, dir, g.gsites, q);
                 for (int k = 0; k < quads; k++)
-                    memcpy(&tab[((size_t)(k * 4 + dir) * n + lg) * 4], &q[4 * k], 4 * sizeof(double));
+                    for (int e = 0; e < 4; e++) tab[((size_t)(k * 4 + dir) * n + lg) * 4 + e] = (real)q[4 * k + e];
             }
         }
     }
-    double4* dev = nullptr;
-    HIP_TRY(hipMalloc(&dev, tab.size() * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(dev, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    real4* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, tab.size() * sizeof(real)));
+    hipError_t e = hipMemcpyAsync(dev, tab.data(), tab.size() * sizeof(real), hipMemcpyHostToDevice, c->stream);
     int rc = QCD_OK;
     if (e != hipSuccess) rc = fail(QCD_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
     if (rc == QCD_OK) rc = convert_slices(c, dev, n, slice0, nslices, true);
@@ -473,13 +473,20 @@ extern "C" {
 
 const char* qcd_last_error(void) { return g_err.c_str(); }
 
+int qcd_precision(void) { return REAL_IS_DOUBLE ? 2 : 1; }
+
 int qcd_create(qcd_ctx** out, const qcd_params* p)
 {
     if (!out || !p) return fail(QCD_ERR_INVALID, "null argument");
     *out = nullptr;
     if (p->group != 2 && p->group != 3) return fail(QCD_ERR_INVALID, "GROUP must be 2 or 3 (got %d)", p->group);
     if (p->nd != 4) return fail(QCD_ERR_UNSUPPORTED, "ND must be 4 (got %d)", p->nd);
-    if (p->precision != 2) return fail(QCD_ERR_UNSUPPORTED, "only double precision (2) is implemented (got %d)", p->precision);
+    // The precision is the library's, fixed when it was built (the reference fixes it when it builds its kernels,
+    // -D PRECISION, SU(N)/suncl/suncl.cpp:3274-3301): 2 = double; 1 = single and 3 = mixed, which the reference's
+    // kernels do not tell apart (float links and arithmetic, fp64 sums)
+    if (REAL_IS_DOUBLE ? (p->precision != 2) : (p->precision != 1 && p->precision != 3))
+        return fail(QCD_ERR_UNSUPPORTED, "this library is built for %s precision (qcd_precision() = %d), the context asks for %d",
+                    REAL_IS_DOUBLE ? "double" : "single", qcd_precision(), p->precision);
     for (int i = 0; i < 4; i++)
         if (p->L[i] < 2) return fail(QCD_ERR_INVALID, "lattice extent L[%d] = %d < 2", i, p->L[i]);
     if (p->L[1] & 1) return fail(QCD_ERR_INVALID, "Ny = %d must be even (checkerboard pairs sites 2h, 2h+1)", p->L[1]);
@@ -503,7 +510,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     {
         // the kernels address a direction's links through 32-bit byte offsets (buffer descriptors)
         const long vh = (long)(p->nx_local + 2 * p->halo) * (p->L[1] / 2) * p->L[2] * p->L[3];
-        const long bytes = 2L * (p->group == 3 ? 6 : 2) * vh * 16;
+        const long bytes = 2L * (p->group == 3 ? 6 : 2) * vh * CB;
         if (bytes >= (1L << 31))
             return fail(QCD_ERR_UNSUPPORTED, "%ld bytes of links per direction on one device exceed 2^31: cut the lattice into more parts", bytes);
     }
@@ -604,7 +611,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     c->stream = c->own_stream;
     tryhip(hipEventCreate(&c->ev0), "hipEventCreate");
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
-    tryhip(hipMalloc(&c->U, c->U_elems * sizeof(double2)), "hipMalloc(links)");
+    tryhip(hipMalloc(&c->U, c->U_elems * sizeof(real2)), "hipMalloc(links)");
     const size_t stw = (size_t)RLX_SLOT_WORDS * g.vh_int * sizeof(unsigned);
     tryhip(hipMalloc(&c->rv.slot0, 2 * stw), "hipMalloc(ranlux)");   // both slots, back to back
     c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_SLOT_WORDS * g.vh_int : nullptr;
@@ -1120,9 +1127,9 @@ static int transfer(qcd_ctx* c, void* host, size_t bytes, int rowsize, bool up)
     const long nsite = (long)g.nx * g.gslice;
     if (!host) return fail(QCD_ERR_INVALID, "null host table");
     if (rowsize < nsite) return fail(QCD_ERR_INVALID, "rowsize %d < owned sites %ld", rowsize, nsite);
-    const size_t need = (size_t)rows * rowsize * 4 * sizeof(double);
-    if (bytes != need) return fail(QCD_ERR_INVALID, "table is %zu bytes, expected rows*rowsize*32 = %zu", bytes, need);
-    double4* dev = nullptr;
+    const size_t need = (size_t)rows * rowsize * 4 * sizeof(real);
+    if (bytes != need) return fail(QCD_ERR_INVALID, "table is %zu bytes, expected rows*rowsize*%d = %zu", bytes, (int)(4 * sizeof(real)), need);
+    real4* dev = nullptr;
     HIP_TRY(hipMalloc(&dev, need));
     hipError_t e = hipSuccess;
     if (up) {
@@ -1238,7 +1245,7 @@ int qcd_rng_state_upload(qcd_ctx* c, const void* host, size_t bytes) { return rn
 size_t qcd_halo_bytes(const qcd_ctx* c)
 {
     if (!c) return 0;
-    return (size_t)c->ncomp * c->g.slice_h * sizeof(double2);
+    return (size_t)c->ncomp * c->g.slice_h * sizeof(real2);
 }
 
 static int halo_op(qcd_ctx* c, int side, int dir, int parity, void* buf, bool pack)
@@ -1256,11 +1263,11 @@ static int halo_op(qcd_ctx* c, int side, int dir, int parity, void* buf, bool pa
     Timed tm(c, 2);
     const dim3 grid(cdiv((long)c->ncomp * c->g.slice_h, MEAS_BLOCK)), block(MEAS_BLOCK);
     if (c->p.group == 3) {
-        if (pack) hipLaunchKernelGGL((k_halo<3, true, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
-        else hipLaunchKernelGGL((k_halo<3, false, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        if (pack) hipLaunchKernelGGL((k_halo<3, true, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (real2*)buf);
+        else hipLaunchKernelGGL((k_halo<3, false, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (real2*)buf);
     } else {
-        if (pack) hipLaunchKernelGGL((k_halo<2, true, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
-        else hipLaunchKernelGGL((k_halo<2, false, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (double2*)buf);
+        if (pack) hipLaunchKernelGGL((k_halo<2, true, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (real2*)buf);
+        else hipLaunchKernelGGL((k_halo<2, false, MEAS_BLOCK>), grid, block, 0, stream, c->U, c->g, dir, parity, slice, (real2*)buf);
     }
     return tm.finish();
 }
@@ -1287,8 +1294,8 @@ int qcd_halo_region(qcd_ctx* c, int side, int owned, int dir, int parity, void**
     const int slice = owned ? (side == 0 ? 1 : c->g.nx) : (side == 0 ? 0 : c->g.nx + 1);
     const size_t base = c->p.group == 3 ? comp_base<3>(c->g, dir, parity) : comp_base<2>(c->g, dir, parity);
     *first = (void*)(c->U + base + (size_t)slice * c->g.slice_h);
-    *piece_bytes = (size_t)c->g.slice_h * sizeof(double2);
-    *pitch_bytes = (size_t)c->g.vh_alloc * sizeof(double2);
+    *piece_bytes = (size_t)c->g.slice_h * sizeof(real2);
+    *pitch_bytes = (size_t)c->g.vh_alloc * sizeof(real2);
     *pieces = c->ncomp;
     return QCD_OK;
 }
@@ -1317,9 +1324,9 @@ int qcd_halo_copy(qcd_ctx* src, int pack_side, qcd_ctx* dst, int recv_side, int 
     if ((rc = check_ctx(dst, true))) return rc;
     if ((rc = edge_buffers(dst))) return rc;
     HIP_TRY(hipStreamWaitEvent(dst->stream, src->edge_ev, 0));
-    const double2* from = src->edge_buf;
+    const real2* from = src->edge_buf;
     if (src->p.device != dst->p.device) {
-        double2* in = dst->edge_buf + bytes / sizeof(double2);
+        real2* in = dst->edge_buf + bytes / sizeof(real2);
         HIP_TRY(hipMemcpyPeerAsync(in, dst->p.device, src->edge_buf, src->p.device, bytes, dst->stream));
         from = in;
     }

@@ -13,9 +13,55 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
+// The precision the library is built for: links, their arithmetic and the heat-bath run in `real`
+// (the reference's hgpu_float, SU(N)/kernel/complex.h:69-92, chosen there by -D PRECISION at kernel
+// build time as well); sums over the lattice are always fp64.
+#ifndef QCD_REAL
+#define QCD_REAL double
+#endif
+
 namespace qcd {
 
+using real = QCD_REAL;
+constexpr bool REAL_IS_DOUBLE = sizeof(real) == 8;
+template <bool D> struct real2_of { using type = double2; };
+template <> struct real2_of<false> { using type = float2; };
+using real2 = real2_of<REAL_IS_DOUBLE>::type;
+__host__ __device__ __forceinline__ real2 make_real2(real x, real y)
+{
+    real2 v;
+    v.x = x;
+    v.y = y;
+    return v;
+}
+constexpr int CB = (int)sizeof(real2);   // bytes of one stored complex number
+// a quad of the reference's device layout (hgpu_float4, SU(N)/suncl/model.cl:140-162)
+template <bool D> struct real4_of { using type = double4; };
+template <> struct real4_of<false> { using type = float4; };
+using real4 = real4_of<REAL_IS_DOUBLE>::type;
+__host__ __device__ __forceinline__ real4 make_real4(real x, real y, real z, real w)
+{
+    real4 v;
+    v.x = x;
+    v.y = y;
+    v.z = z;
+    v.w = w;
+    return v;
+}
+
 struct MathLib {
+    __device__ __forceinline__ float rcp(float x) const { return 1.0f / x; }
+    __device__ __forceinline__ float sqrt_of(float x) const { return sqrtf(x); }
+    __device__ __forceinline__ void sqrt_rcp(float x, float& s, float& is) const
+    {
+        s = sqrtf(x);
+        is = 1.0f / s;
+    }
+    __device__ __forceinline__ float log_of(float x) const { return logf(x); }
+    template <class T, class = typename std::enable_if<std::is_same<T, float>::value>::type>
+    __device__ __forceinline__ float div(T a, T b) const { return a / b; }   // both float: mixed arguments take the fp64 form
     __device__ __forceinline__ double rcp(double x) const { return 1.0 / x; }
     __device__ __forceinline__ double sqrt_of(double x) const { return sqrt(x); }
     // s = sqrt(x), is = 1/s
@@ -46,6 +92,33 @@ struct MathFast {
             t[j] = make_double2(inv, -log(inv));
         }
     }
+
+    // single precision: the hardware's reciprocal, reciprocal square root and logarithm (1 ulp) with one
+    // correction step where a product of the results is formed
+    __device__ __forceinline__ float rcp(float x) const
+    {
+        const float y = __builtin_amdgcn_rcpf(x);
+        return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+    }
+    template <class T, class = typename std::enable_if<std::is_same<T, float>::value>::type>
+    __device__ __forceinline__ float div(T a, T b) const { return a * rcp(b); }
+    __device__ __forceinline__ void sqrt_rcp(float x, float& s, float& is) const
+    {
+        const float y = __builtin_amdgcn_rsqf(x);
+        float g = x * y;
+        const float h = 0.5f * y;
+        g = __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+        s = g;
+        is = rcp(g);
+    }
+    __device__ __forceinline__ float sqrt_of(float x) const
+    {
+        const float y = __builtin_amdgcn_rsqf(x);
+        float g = x * y;
+        g = __builtin_fmaf(__builtin_fmaf(-g, g, x), 0.5f * y, g);
+        return (x == 0.0f) ? 0.0f : g;
+    }
+    __device__ __forceinline__ float log_of(float x) const { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
     // normal, positive x well inside the exponent range (here: norms of 2x2 blocks, 1e-3 .. 1e2)
     __device__ __forceinline__ double rcp(double x) const

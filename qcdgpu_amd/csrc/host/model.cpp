@@ -270,7 +270,11 @@ void model::lattice_init(void)
 {
     if (INIT == 0) lattice_load_state();   // run parameters from the state file's header (suncl.cpp:695)
     if (lattice_nd != 4) throw model_error("ND must be 4");
-    if (precision != model_precision_double) throw model_error("only double precision is implemented");
+    // the precision is the library's (the reference builds its kernels for one precision, -D PRECISION,
+    // SU(N)/suncl/suncl.cpp:3274-3301): qcdgpu is linked with the double library, qcdgpu_f32 with the single one
+    if ((qcd_precision() == 2) != (precision == model_precision_double))
+        throw model_error(qcd_precision() == 2 ? "this program is linked with the double-precision library: run qcdgpu_f32 for single or mixed precision"
+                                               : "this program is linked with the single-precision library: run qcdgpu for double precision");
     if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
     if ((get_Fmunu || get_F0mu) && lattice_group == 2) {
         // Fmunu_defaults, SU(N)/suncl/suncl.cpp:2094-2101: Pauli matrices, first index 3 or 1, second 2
@@ -303,7 +307,7 @@ void model::lattice_init(void)
         p.group = lattice_group;
         p.nd = lattice_nd;
         for (int i = 0; i < 4; i++) p.L[i] = lattice_full_size[i];
-        p.precision = 2;
+        p.precision = (int)precision_word();
         p.beta = BETA;
         p.nhit = NHIT;
         p.start_mode = (ints == model_start_hot) ? QCD_START_HOT : (ints == model_start_gid ? QCD_START_GID : QCD_START_COLD);
@@ -582,7 +586,7 @@ std::vector<unsigned int> model::lattice_make_bin_header(void) const   // suncl.
     r[k++] = (unsigned int)NHIT;
     r[k++] = (unsigned int)wilson_R;
     r[k++] = (unsigned int)wilson_T;
-    r[k++] = 2u;   // double precision
+    r[k++] = precision_word();   // model::convert_precision_to_uint, SU(N)/suncl/suncl.cpp:732-737
     split_double(BETA, r[k], r[k + 1]); k += 2;
     split_double(PHI, r[k], r[k + 1]); k += 2;
     split_double(OMEGA, r[k], r[k + 1]); k += 2;
@@ -629,7 +633,7 @@ bool model::lattice_load_bin_header(const unsigned int* head)   // suncl.cpp:199
     NHIT = (int)head[k++];
     wilson_R = (int)head[k++];
     wilson_T = (int)head[k++];
-    if (head[k++] != 2u) return false;   // only double-precision states
+    if (head[k++] != precision_word()) return false;   // a state of another precision: its link table has other element sizes
     BETA = join_double(head[k], head[k + 1]); k += 2;
     PHI = join_double(head[k], head[k + 1]); k += 2;
     OMEGA = join_double(head[k], head[k + 1]); k += 2;
@@ -695,17 +699,18 @@ void model::lattice_save_state(void)
     const int rows = (lattice_group == 3) ? 12 : 4;
     const unsigned int rs = table_row_size();
     const size_t gslice = (size_t)lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
-    std::vector<double> table((size_t)rows * rs * 4, 0.0);
+    const size_t qb = 4 * real_bytes();   // bytes of a quad: double4 or float4 rows (SU(N)/suncl/model.cl:140-162)
+    std::vector<unsigned char> table((size_t)rows * rs * qb, 0);
     size_t x0 = 0;
     for (auto& s : SubLat) {
         const size_t nloc = (size_t)s.Nx * gslice;
-        std::vector<double> part((size_t)rows * nloc * 4);
-        check(qcd_download(s.ctx, part.data(), part.size() * sizeof(double), (int)nloc), "qcd_download");
+        std::vector<unsigned char> part((size_t)rows * nloc * qb);
+        check(qcd_download(s.ctx, part.data(), part.size(), (int)nloc), "qcd_download");
         for (int r = 0; r < rows; r++)
-            memcpy(&table[((size_t)r * rs + x0 * gslice) * 4], &part[(size_t)r * nloc * 4], nloc * 4 * sizeof(double));
+            memcpy(&table[((size_t)r * rs + x0 * gslice) * qb], &part[(size_t)r * nloc * qb], nloc * qb);
         x0 += (size_t)s.Nx;
     }
-    fwrite(table.data(), 4 * sizeof(double), (size_t)rows * rs, stream);
+    fwrite(table.data(), qb, (size_t)rows * rs, stream);
 
     // per-thread generator state in global stream order
     const size_t NS = (size_t)lattice_full_size[0] * gslice / 2;
@@ -782,7 +787,7 @@ void model::lattice_load_state(void)
         if (plq_sec) need += 16ull * state_sizes_[2];
         if (get_wilson_loop) need += 8ull * state_sizes_[1];
         if (PL_level > 0) need += 16ull * state_sizes_[3];
-        need += 32ull * ((lattice_group == 3) ? 12 : 4) * table_row_size();
+        need += 4ull * real_bytes() * ((lattice_group == 3) ? 12 : 4) * table_row_size();
         const long at = ftell(stream);
         fseek(stream, 0, SEEK_END);
         const unsigned long long have = (unsigned long long)ftell(stream);
@@ -832,8 +837,9 @@ void model::lattice_load_state(void)
     const int rows = (lattice_group == 3) ? 12 : 4;
     const unsigned int rs = table_row_size();
     const size_t gslice = (size_t)lattice_full_size[1] * lattice_full_size[2] * lattice_full_size[3];
-    std::vector<double> table((size_t)rows * rs * 4);
-    ok = ok && fread(table.data(), 4 * sizeof(double), (size_t)rows * rs, stream) == (size_t)rows * rs;
+    const size_t qb = 4 * real_bytes();
+    std::vector<unsigned char> table((size_t)rows * rs * qb);
+    ok = ok && fread(table.data(), qb, (size_t)rows * rs, stream) == (size_t)rows * rs;
     if (!ok) {
         fclose(stream);
         throw model_error("state file is truncated: " + file);
@@ -841,11 +847,11 @@ void model::lattice_load_state(void)
     size_t x0 = 0;
     for (auto& s : SubLat) {
         const size_t nloc = (size_t)s.Nx * gslice;
-        std::vector<double> part((size_t)rows * nloc * 4);
+        std::vector<unsigned char> part((size_t)rows * nloc * qb);
         for (int r = 0; r < rows; r++)
-            memcpy(&part[(size_t)r * nloc * 4], &table[((size_t)r * rs + x0 * gslice) * 4], nloc * 4 * sizeof(double));
+            memcpy(&part[(size_t)r * nloc * qb], &table[((size_t)r * rs + x0 * gslice) * qb], nloc * qb);
         check(qcd_init_lattice(s.ctx), "qcd_init_lattice");   // tables of the start mode (gid), stream seeds
-        check(qcd_upload(s.ctx, part.data(), part.size() * sizeof(double), (int)nloc), "qcd_upload");
+        check(qcd_upload(s.ctx, part.data(), part.size(), (int)nloc), "qcd_upload");
         x0 += (size_t)s.Nx;
     }
     // generator state (absent in files the reference wrote: the streams then start from their seeds)

@@ -107,6 +107,9 @@ public:
     int lattice_full_size[4] = {32, 32, 32, 32};
     int lattice_domain_size[4] = {32, 32, 32, 32};
     enum_model_precision precision = model_precision_double;
+    // model::convert_precision_to_uint (SU(N)/suncl/suncl.cpp:732-737) and the bytes of one stored real
+    unsigned int precision_word() const { return precision == model_precision_double ? 2u : (precision == model_precision_mixed ? 3u : 1u); }
+    size_t real_bytes() const { return precision == model_precision_double ? 8 : 4; }
     int INIT = 1;
     int NAV = 0;
     int ITER = 2;

@@ -22,7 +22,8 @@ int main(int argc, char** argv)
         model0->lattice_nd = 4;
         model0->lattice_group = 3;
         for (int i = 0; i < 4; i++) model0->lattice_full_size[i] = model0->lattice_domain_size[i] = 32;
-        model0->precision = model::model_precision_double;
+        // SU(N)/QCDGPU.cpp:178-179 picks the precision in the source; here it is the library the program is linked with
+        model0->precision = (qcd_precision() == 2) ? model::model_precision_double : model::model_precision_single;
         model0->INIT = 1;
         model0->NAV = 0;
         model0->ITER = 2;

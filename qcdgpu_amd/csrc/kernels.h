@@ -335,22 +335,26 @@ struct GidSource {
 
 // cos(2 pi r), sin(2 pi r) for r in [0, 1): the reference forms 2*pi*r in fp64 and calls cos/sin;
 // cospi/sincospi reduce the argument exactly and are half the instructions
-__device__ __forceinline__ double cos_2pi(float r) { return cospi(2.0 * (double)r); }
+__device__ __forceinline__ double cos_2pi_of(float r, double) { return cospi(2.0 * (double)r); }
+__device__ __forceinline__ float cos_2pi_of(float r, float) { return cospif(2.0f * r); }
+__device__ __forceinline__ real cos_2pi(float r) { return cos_2pi_of(r, real()); }
+__device__ __forceinline__ void sincos_2pi(float r, double& s, double& c) { sincospi(2.0 * (double)r, &s, &c); }
+__device__ __forceinline__ void sincos_2pi(float r, float& s, float& c) { sincospif(2.0f * r, &s, &c); }
 
 // `m`: where reciprocal, square root and logarithm come from (fastmath.h).  beta_inv = 1 / beta.
 template <bool GID, class Rng, class Math>
-__device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, double beta_inv, int nhit, Rng& rng,
+__device__ __forceinline__ bool heatbath_su2(const su2& stap, real beta, real beta_inv, int nhit, Rng& rng,
                                              const Math& m, su2& out)
 {
-    const double Mx = (stap.e[0][0].re + stap.e[1][1].re);
-    const double My = (stap.e[0][0].im - stap.e[1][1].im);
-    const double Mz = (stap.e[0][1].re - stap.e[1][0].re);
-    const double Mw = (stap.e[0][1].im + stap.e[1][0].im);
+    const real Mx = (stap.e[0][0].re + stap.e[1][1].re);
+    const real My = (stap.e[0][0].im - stap.e[1][1].im);
+    const real Mz = (stap.e[0][1].re - stap.e[1][0].re);
+    const real Mw = (stap.e[0][1].im + stap.e[1][0].im);
 
-    double det, idet;
+    real det, idet;
     m.sqrt_rcp(Mx * Mx + My * My + Mz * Mz + Mw * Mw, det, idet);
-    const double bdet = beta * det;
-    const double ibdet = beta_inv * idet;   // the reference divides by bdet; <= 1 ulp apart
+    const real bdet = beta * det;
+    const real ibdet = beta_inv * idet;   // the reference divides by bdet; <= 1 ulp apart
 
     su2 aH;
     aH.e[0][0] = mk(Mx * idet, -My * idet);
@@ -359,56 +363,72 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, doubl
     aH.e[1][0] = mk(-aH.e[0][1].re, aH.e[0][1].im);
 
     bool flag = false;
-    double delta = 0.0;
+    real delta = 0;
     float rnd[4];
     if (GID) {
         // INTS = 2: the first trial is always accepted (update_su2.cpp:87-90)
         rng.draw4(rnd);
-        const double cosrnd = cos_2pi(rnd[1]);
+        const real cosrnd = cos_2pi(rnd[1]);
         delta = cosrnd * cosrnd * ibdet;
         flag = true;
     } else {
-        const float ibdet32 = m.rcp32(bdet);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;  // r0, r1, r2 of the accepted trial
-        int i = 0;
-        while ((i < nhit) && !flag) {
-            rng.draw4(rnd);
-            const float c32 = __builtin_amdgcn_cosf(rnd[1]);
-            const float l0 = __builtin_amdgcn_logf(1.0f - rnd[0]) * 0.6931471805599453f;
-            const float l2 = __builtin_amdgcn_logf(1.0f - rnd[2]) * 0.6931471805599453f;
-            const float d32 = -(l0 + c32 * c32 * l2) * ibdet32;
-            const float r3sq = rnd[3] * rnd[3];
-            const float t32 = 1.0f - 0.5f * d32 - r3sq;
-            const float margin = ibdet32 * (4.0f * QCD_SCREEN_LOG_REL * (fabsf(l0) + fabsf(l2)) +
-                                            4.0f * QCD_SCREEN_COS_ABS * fabsf(l2) + 1.0e-6f) +
-                                 4.0e-6f * fabsf(d32) + 4.0e-6f;
-            bool acc = t32 > margin;
-            if (fabsf(t32) <= margin) {
-                const double cosrnd = cos_2pi(rnd[1]);
-                const double d = -(m.log_of(1.0 - rnd[0]) + cosrnd * cosrnd * m.log_of(1.0 - rnd[2])) * ibdet;
-                acc = (r3sq <= (1.0 - 0.5 * d));
+        if constexpr (REAL_IS_DOUBLE) {
+            const float ibdet32 = m.rcp32(bdet);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;  // r0, r1, r2 of the accepted trial
+            int i = 0;
+            while ((i < nhit) && !flag) {
+                rng.draw4(rnd);
+                const float c32 = __builtin_amdgcn_cosf(rnd[1]);
+                const float l0 = __builtin_amdgcn_logf(1.0f - rnd[0]) * 0.6931471805599453f;
+                const float l2 = __builtin_amdgcn_logf(1.0f - rnd[2]) * 0.6931471805599453f;
+                const float d32 = -(l0 + c32 * c32 * l2) * ibdet32;
+                const float r3sq = rnd[3] * rnd[3];
+                const float t32 = 1.0f - 0.5f * d32 - r3sq;
+                const float margin = ibdet32 * (4.0f * QCD_SCREEN_LOG_REL * (fabsf(l0) + fabsf(l2)) +
+                                                4.0f * QCD_SCREEN_COS_ABS * fabsf(l2) + 1.0e-6f) +
+                                     4.0e-6f * fabsf(d32) + 4.0e-6f;
+                bool acc = t32 > margin;
+                if (fabsf(t32) <= margin) {
+                    const double cosrnd = cos_2pi(rnd[1]);
+                    const double d = -(m.log_of(1.0 - rnd[0]) + cosrnd * cosrnd * m.log_of(1.0 - rnd[2])) * ibdet;
+                    acc = (r3sq <= (1.0 - 0.5 * d));
+                }
+                if (acc) {
+                    flag = true;
+                    a0 = rnd[0];
+                    a1 = rnd[1];
+                    a2 = rnd[2];
+                }
+                i++;
             }
-            if (acc) {
-                flag = true;
-                a0 = rnd[0];
-                a1 = rnd[1];
-                a2 = rnd[2];
+            if (flag) {
+                const double cosrnd = cos_2pi(a1);
+                delta = -(m.log_of(1.0 - a0) + cosrnd * cosrnd * m.log_of(1.0 - a2)) * ibdet;
             }
-            i++;
-        }
-        if (flag) {
-            const double cosrnd = cos_2pi(a1);
-            delta = -(m.log_of(1.0 - a0) + cosrnd * cosrnd * m.log_of(1.0 - a2)) * ibdet;
+        } else {
+            // single precision: the test as the reference's float build evaluates it (hgpu_float arithmetic,
+            // SU(N)/suncl/su3_update_cl.cl:597-649), with the hardware logarithm
+            int i = 0;
+            while ((i < nhit) && !flag) {
+                rng.draw4(rnd);
+                const float cosrnd = cos_2pi(rnd[1]);
+                const float d = -(m.log_of(1.0f - rnd[0]) + cosrnd * cosrnd * m.log_of(1.0f - rnd[2])) * ibdet;
+                if (rnd[3] * rnd[3] <= (1.0f - 0.5f * d)) {
+                    flag = true;
+                    delta = d;
+                }
+                i++;
+            }
         }
     }
     if (flag) {
         rng.draw2(rnd);
-        const double cosal = 1.0 - delta;
-        const double costh = 2.0 * rnd[0] - 1.0;
-        const double sinth = m.sqrt_of(1.0 - costh * costh);
-        const double sinal = m.sqrt_of(1.0 - cosal * cosal);
-        double sinphi, cosphi;
-        sincospi(2.0 * (double)rnd[1], &sinphi, &cosphi);
+        const real cosal = (real)1 - delta;
+        const real costh = (real)2 * rnd[0] - (real)1;
+        const real sinth = m.sqrt_of((real)1 - costh * costh);
+        const real sinal = m.sqrt_of((real)1 - cosal * cosal);
+        real sinphi, cosphi;
+        sincos_2pi(rnd[1], sinphi, cosphi);
         su2 c;
         c.e[0][0] = mk(cosal, sinal * costh);
         c.e[0][1] = mk(sinal * sinth * sinphi, sinal * sinth * cosphi);
@@ -424,7 +444,7 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, double beta, doubl
 // change under the embedded SU(2) element (the other products of the reference are with exact
 // zeros and ones).
 template <int P, int Q, bool GID, class Rng, class Math>
-__device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, double beta_inv, int nhit, Rng& rng,
+__device__ __forceinline__ void cm_step(su3& U, const su3& A, real beta, real beta_inv, int nhit, Rng& rng,
                                         const Math& m)
 {
     su2 blk;
@@ -444,7 +464,7 @@ __device__ __forceinline__ void cm_step(su3& U, const su3& A, double beta, doubl
 }
 
 template <bool GID, class Rng, class Math>
-__device__ __forceinline__ void update_link(su3& U, const su3& A, double beta, double beta_inv, int nhit, Rng& rng,
+__device__ __forceinline__ void update_link(su3& U, const su3& A, real beta, real beta_inv, int nhit, Rng& rng,
                                             const Math& m)
 {
 #ifdef QCD_ABL_HB  // diagnostic build: no heat-bath, keeps loads, staple products and the store
@@ -460,7 +480,7 @@ __device__ __forceinline__ void update_link(su3& U, const su3& A, double beta, d
 // SU(2): the new link does not depend on the old one; unchanged when no trial is accepted
 // (update_su2.cpp:121-125 with final = 1, SU(N)/suncpp/Update/sun_update.h:94)
 template <bool GID, class Rng, class Math>
-__device__ __forceinline__ void update_link(su2& U, const su2& A, double beta, double beta_inv, int nhit, Rng& rng,
+__device__ __forceinline__ void update_link(su2& U, const su2& A, real beta, real beta_inv, int nhit, Rng& rng,
                                             const Math& m)
 {
     su2 r;
@@ -475,11 +495,11 @@ __device__ __forceinline__ void update_link(su2& U, const su2& A, double beta, d
 template <class Math>
 __device__ __forceinline__ su2 overrelax_su2(const su2& blk, const Math& m)
 {
-    const double Mx = (blk.e[0][0].re + blk.e[1][1].re);
-    const double My = (blk.e[0][0].im - blk.e[1][1].im);
-    const double Mz = (blk.e[0][1].re - blk.e[1][0].re);
-    const double Mw = (blk.e[0][1].im + blk.e[1][0].im);
-    double det, idet;
+    const real Mx = (blk.e[0][0].re + blk.e[1][1].re);
+    const real My = (blk.e[0][0].im - blk.e[1][1].im);
+    const real Mz = (blk.e[0][1].re - blk.e[1][0].re);
+    const real Mw = (blk.e[0][1].im + blk.e[1][0].im);
+    real det, idet;
     m.sqrt_rcp(Mx * Mx + My * My + Mz * Mz + Mw * Mw, det, idet);
     su2 aH;
     aH.e[0][0] = mk(Mx * idet, -My * idet);
@@ -524,7 +544,7 @@ __device__ __forceinline__ void overrelax_link(su2& U, const su2& A, const Math&
 
 // hb = 16 * half index of x, par = parity of x (wave-uniform)
 template <int GROUP, int DIR>
-__device__ __forceinline__ mat<GROUP> staple(const double2* __restrict__ U, const Geom& g, const int hb,
+__device__ __forceinline__ mat<GROUP> staple(const real2* __restrict__ U, const Geom& g, const int hb,
                                              const NbrOff& n, const int par)
 {
     using M = mat<GROUP>;
@@ -581,7 +601,7 @@ __device__ __forceinline__ cplx dot3c(cplx a1, cplx a2, cplx a3, cplx b1, cplx b
 }
 
 struct raw_link {
-    double2 c[6];
+    real2 c[6];
 };
 #ifndef QCD_NU_AUX
 #define QCD_NU_AUX 0
@@ -592,7 +612,7 @@ __device__ __forceinline__ raw_link issue_link(__amdgpu_buffer_rsrc_t r, const G
     raw_link l;
 #pragma unroll
     for (int c = 0; c < 6; c++)
-        l.c[c] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, c * g.vh_alloc * 16, AUX));
+        l.c[c] = buf_load_c<AUX>(r, byte_off, c * g.vh_alloc * CB);
     return l;
 }
 __device__ __forceinline__ rows2 as_rows2(const raw_link& l)
@@ -679,7 +699,7 @@ __host__ __device__ constexpr int staple_aux(int mu, int nu, int which)
     return ((nt_mask(mu) >> (3 * which + k)) & 1u) ? AUX_NT : ((which == 1 || which == 3) ? 0 : QCD_NU_AUX);
 }
 template <int DIR, int TERM>
-__device__ __forceinline__ raw_pair issue_ab(const double2* __restrict__ U, const Geom& g, const int hb,
+__device__ __forceinline__ raw_pair issue_ab(const real2* __restrict__ U, const Geom& g, const int hb,
                                              const NbrOff& n, const int par)
 {
     constexpr int k = TERM / 2;
@@ -697,7 +717,7 @@ __device__ __forceinline__ raw_pair issue_ab(const double2* __restrict__ U, cons
     return t;
 }
 template <int DIR, int TERM>
-__device__ __forceinline__ raw_link issue_c(const double2* __restrict__ U, const Geom& g, const int hb,
+__device__ __forceinline__ raw_link issue_c(const real2* __restrict__ U, const Geom& g, const int hb,
                                             const NbrOff& n, const int par)
 {
     constexpr int k = TERM / 2;
@@ -766,7 +786,7 @@ struct StaplePipe {
 #endif
 };
 template <int DIR, int TERM>
-__device__ __forceinline__ void issue_next_ab(StaplePipe& sp, const double2* __restrict__ U, const Geom& g, const int hb,
+__device__ __forceinline__ void issue_next_ab(StaplePipe& sp, const real2* __restrict__ U, const Geom& g, const int hb,
                                               const NbrOff& n, const int par)
 {
 #ifdef QCD_PAIR_MU
@@ -789,7 +809,7 @@ __device__ __forceinline__ void issue_next_ab(StaplePipe& sp, const double2* __r
 // `between` runs after the first product, where the next term's first loads are requested (the
 // last term has none: the caller's own requests take their place)
 template <int DIR, int TERM, class Hook = NoHook>
-__device__ __forceinline__ void pipe_step(StaplePipe& sp, const double2* __restrict__ U,
+__device__ __forceinline__ void pipe_step(StaplePipe& sp, const real2* __restrict__ U,
                                            const Geom& g, const int hb, const NbrOff& n, const int par,
                                            Hook between = Hook())
 {
@@ -806,7 +826,7 @@ __device__ __forceinline__ void pipe_step(StaplePipe& sp, const double2* __restr
 // the pipeline in two parts, so that the caller can request what it needs next (its own link,
 // the random stream's state) before the last term's arithmetic
 template <int DIR>
-__device__ __forceinline__ void staple_pipe_head(StaplePipe& sp, const double2* __restrict__ U, const Geom& g,
+__device__ __forceinline__ void staple_pipe_head(StaplePipe& sp, const real2* __restrict__ U, const Geom& g,
                                                  const int hb, const NbrOff& n, const int par)
 {
     sp.stap = zero<3>();
@@ -819,7 +839,7 @@ __device__ __forceinline__ void staple_pipe_head(StaplePipe& sp, const double2* 
     pipe_step<DIR, 4>(sp, U, g, hb, n, par);
 }
 template <int DIR, class Hook>
-__device__ __forceinline__ void staple_pipe_tail(StaplePipe& sp, const double2* __restrict__ U, const Geom& g,
+__device__ __forceinline__ void staple_pipe_tail(StaplePipe& sp, const real2* __restrict__ U, const Geom& g,
                                                  const int hb, const NbrOff& n, const int par, Hook between)
 {
     pipe_step<DIR, 5>(sp, U, g, hb, n, par, between);
@@ -868,7 +888,7 @@ constexpr int DRAW_SLOTS = 64;
 constexpr int DRAW_SLOT_STRIDE = 16;   // 128 bytes
 
 struct UpdArgs {
-    double2* U;
+    real2* U;
     Geom g;
     int parity;
     int nhit;
@@ -926,7 +946,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     ArgPtr ap = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ap));   // a fresh, opaque pointer every trip: nothing read through it is carried over
     if (wb >= ap->nblocks) break;
-    double2* __restrict__ U = ap->U;
+    real2* __restrict__ U = ap->U;
     Geom g;   // member by member: a whole-struct copy out of the argument segment goes through scratch
     g.nx = ap->g.nx; g.ny = ap->g.ny; g.nz = ap->g.nz; g.nt = ap->g.nt;
     g.halo = ap->g.halo; g.x0 = ap->g.x0; g.nyh = ap->g.nyh; g.slice_h = ap->g.slice_h;
@@ -936,7 +956,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     g.ux0 = ap->g.ux0; g.unx = ap->g.unx;
     const int parity = ap->parity;
     const int nhit = ap->nhit;
-    const double beta_eff = ap->beta_eff;
+    const real beta_eff = (real)ap->beta_eff;
     RlxView rv;
     rv.slot0 = ap->rv.slot0; rv.slot1 = ap->rv.slot1; rv.ctl = nullptr; rv.cur = ap->rv.cur;
     rv.ns = ap->rv.ns; rv.q = ap->rv.q; rv.rem = ap->rv.rem;
@@ -944,7 +964,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     Site x;
     int t;  // stream number = the site pair's half index in the slab
     if (site_of_workgroup<BLOCK>(g, wb, threadIdx.x, parity, x, t)) {
-        const int hb = half_index(g, x) * 16;
+        const int hb = half_index(g, x) * CB;
 #ifdef QCD_ABL_LOCAL  // diagnostic build: every neighbour is the site itself (minimal traffic, wrong physics)
         NbrOff nbr;
         nbr.f0 = nbr.f1 = nbr.f2 = nbr.f3 = nbr.b0 = nbr.b1 = nbr.b2 = nbr.b3 = 0;
@@ -996,9 +1016,9 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             for (int k = 0; k < 4; k++) src.trial[k] = gidr[k * n + lg];
             src.accept[0] = gidr[4 * n + lg];
             src.accept[1] = gidr[5 * n + lg];
-            update_link<true>(Ul, A, beta_eff, ap->beta_inv, nhit, src, fm);
+            update_link<true>(Ul, A, beta_eff, (real)ap->beta_inv, nhit, src, fm);
         } else {
-            update_link<false>(Ul, A, beta_eff, ap->beta_inv, nhit, rs, fm);
+            update_link<false>(Ul, A, beta_eff, (real)ap->beta_inv, nhit, rs, fm);
             QCD_STAMP(3);
             used += (unsigned long long)rs.close();
             store_link_buf(r_own, g, hb, Ul);
@@ -1037,7 +1057,7 @@ __device__ __forceinline__ SiteRef site_ref(const Geom& g, int wb, int tid, int 
     int t = 0;
     (void)site_of_workgroup<BLOCK>(g, wb, tid, parity, x, t);   // every block of the launch is full
     SiteRef r;
-    r.hb = half_index(g, x) * 16;
+    r.hb = half_index(g, x) * CB;
     r.nbr = neighbour_offsets(g, x);
     r.stream = t;
     return r;
@@ -1091,7 +1111,7 @@ constexpr int GH_SLOTS = 2;     // hand-over slots per team
 template <int TEAMS>
 struct GhShared {
     static constexpr int PER = GH_SIDE / TEAMS;             // wavefronts of either kind per team
-    double2 stap[TEAMS][GH_SLOTS][PER][9][64];              // partial staple sums: 18 reals per lane
+    real2 stap[TEAMS][GH_SLOTS][PER][9][64];              // partial staple sums: 18 reals per lane
     float rbuf[GH_SIDE][RLX_ROWS * 64];              // random numbers of the heat-bath wavefronts
     double2 logtab[LOG_TABLE_ENTRIES];
     unsigned full_seq[TEAMS][GH_SLOTS][PER];                // gather wavefront j has put block (full_seq - 1) into the slot
@@ -1156,9 +1176,9 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
                 QCD_GH_SPIN(0);
             }
         }
-        double2* dst = &sh.stap[team][s][j][0][lane];
+        real2* dst = &sh.stap[team][s][j][0][lane];
 #pragma unroll
-        for (int k = 0; k < 9; k++) dst[k * 64] = make_double2(stap.e[k / 3][k % 3].re, stap.e[k / 3][k % 3].im);
+        for (int k = 0; k < 9; k++) dst[k * 64] = make_real2(stap.e[k / 3][k % 3].re, stap.e[k / 3][k % 3].im);
         __hip_atomic_store(&sh.full_seq[team][s][j], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!has_next) break;
         cur = nxt;
@@ -1234,11 +1254,11 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
                     __builtin_amdgcn_s_sleep(4);
                     QCD_GH_SPIN(1);
                 }
-                const double2* src = &sh.stap[team][s][m][0][lane];
+                const real2* src = &sh.stap[team][s][m][0][lane];
                 su3 P;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
-                    const double2 v = src[k * 64];
+                    const real2 v = src[k * 64];
                     P.e[k / 3][k % 3] = mk(v.x, v.y);
                 }
                 if (m == 0) A = P;
@@ -1248,7 +1268,7 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
             __hip_atomic_store(&sh.free_seq[team][s], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             pin(own);
             su3 Ul = as_su3(own);
-            update_link<false>(Ul, A, a.beta_eff, a.beta_inv, a.nhit, rs, fm);
+            update_link<false>(Ul, A, (real)a.beta_eff, (real)a.beta_inv, a.nhit, rs, fm);
             used += (unsigned long long)rs.close();
             if (a.edge_local > 0 && wb / (g.nzr * g.ntr) < a.edge_local) {
                 store_link_buf<STORE_AUX_THROUGH>(r_own, g, cur.hb, Ul);
@@ -1267,12 +1287,12 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
 // overrelaxation pass over the links of direction DIR on the sites of one parity: same gather
 // as the heat-bath pass, no random numbers
 template <int GROUP, int DIR, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void k_overrelax(double2* __restrict__ U, const Geom g, const int parity)
+__global__ __launch_bounds__(BLOCK, 2) void k_overrelax(real2* __restrict__ U, const Geom g, const int parity)
 {
     Site x;
     int t;
     if (!site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) return;
-    const int hb = half_index(g, x) * 16;
+    const int hb = half_index(g, x) * CB;
     const NbrOff nbr = neighbour_offsets(g, x);
     const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(U, g, DIR, parity);
     MathFast fm;
@@ -1296,7 +1316,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_overrelax(double2* __restrict__ U,
 // (xy, xz, yz) and the 3 space-time planes (xt, yt, zt); ReTr[U_mu(x) U_nu(x+mu) U_mu(x+nu)^+ U_nu(x)^+]
 
 template <int GROUP>
-__device__ __forceinline__ double retr_plaquette(const double2* __restrict__ U, const Geom& g, const Site& x,
+__device__ __forceinline__ double retr_plaquette(const real2* __restrict__ U, const Geom& g, const Site& x,
                                                  int mu, int nu)
 {
     using M = mat<GROUP>;
@@ -1345,7 +1365,7 @@ __device__ __forceinline__ double retr_plaquette_su3_from(const rows2& a, const 
     }
     return re;
 }
-__device__ __forceinline__ double retr_plaquette_su3(const double2* __restrict__ U, const Geom& g, const unsigned ob,
+__device__ __forceinline__ double retr_plaquette_su3(const real2* __restrict__ U, const Geom& g, const unsigned ob,
                                                      const NbrOff& n, const int mu, const int nu,
                                                      const rows2& a, const rows2& d)
 {
@@ -1408,7 +1428,7 @@ __device__ __forceinline__ void block_reduce_store(double a, double b, double2* 
 // site_vals (may be null): the (space-like, time-like) sums of every site, index par * vh_int + interior
 // half index, for the profiles below.
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__ U, const Geom g,
+__global__ __launch_bounds__(BLOCK) void k_plaquette(const real2* __restrict__ U, const Geom g,
                                                      double2* __restrict__ partial, double2* __restrict__ site_vals)
 {
     double spat = 0.0, temp = 0.0;
@@ -1416,8 +1436,8 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
     if (measurement_site<BLOCK>(g, x)) {
         const int par = site_parity(g, x);
         if constexpr (GROUP == 3) {
-            const unsigned hb = (unsigned)half_index(g, x) * 16u;
-            const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * 16u;
+            const unsigned hb = (unsigned)half_index(g, x) * (unsigned)CB;
+            const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * (unsigned)CB;
             const unsigned own_off = (par ? pbytes : 0u) + hb, other_off = (par ? 0u : pbytes) + hb;
             const NbrOff n = neighbour_offsets(g, x);
             rows2 own[4];
@@ -1456,7 +1476,7 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const double2* __restrict__
 // site_vals outputs.  (Workgroups shaped as tiles in (z, t) instead of rows in storage order, and
 // workgroups of 512, were measured as well: 144 and 151 us per call against 141.)
 template <int BLOCK, int XSEG>
-__global__ __launch_bounds__(BLOCK) void k_plaquette_march(const double2* __restrict__ U, const Geom g,
+__global__ __launch_bounds__(BLOCK) void k_plaquette_march(const real2* __restrict__ U, const Geom g,
                                                            double2* __restrict__ partial, double2* __restrict__ site_vals)
 {
     double spat = 0.0, temp = 0.0;
@@ -1471,11 +1491,11 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette_march(const double2* __rest
         x.z = r % g.nz;
         x.t = r / g.nz;
         x.xs = seg * XSEG;
-        const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * 16u;
+        const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * (unsigned)CB;
         rows2 own[4];
         {
             const int par = site_parity(g, x);
-            const unsigned own_off = (par ? pbytes : 0u) + (unsigned)half_index(g, x) * 16u;
+            const unsigned own_off = (par ? pbytes : 0u) + (unsigned)half_index(g, x) * (unsigned)CB;
 #pragma unroll
             for (int d = 0; d < 4; d++) own[d] = as_rows2(issue_link(link_rsrc_both<3>(U, g, d), g, (int)own_off));
         }
@@ -1483,7 +1503,7 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette_march(const double2* __rest
 #pragma unroll 1
         for (int s = 0; s < steps; s++) {
             const int par = site_parity(g, x);
-            const unsigned hb = (unsigned)half_index(g, x) * 16u;
+            const unsigned hb = (unsigned)half_index(g, x) * (unsigned)CB;
             const unsigned other_off = (par ? 0u : pbytes) + hb;
             const NbrOff n = neighbour_offsets(g, x);
             // the next site's y, z, t links (as this site's x neighbours), requested first
@@ -1513,7 +1533,7 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette_march(const double2* __rest
                 // on to x + xhat: its y, z, t links are here, its x link is requested now
                 x.xs++;
                 const int par2 = par ^ 1;
-                const unsigned own2 = (par2 ? pbytes : 0u) + (unsigned)half_index(g, x) * 16u;
+                const unsigned own2 = (par2 ? pbytes : 0u) + (unsigned)half_index(g, x) * (unsigned)CB;
                 own[0] = as_rows2(issue_link(link_rsrc_both<3>(U, g, 0), g, (int)own2));
 #pragma unroll
                 for (int d = 1; d < 4; d++) own[d] = as_rows2(nxt[d - 1]);
@@ -1561,7 +1581,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce(const double2* __restrict__ pa
 // partial[block] = (sum over the block's sites and the three directions, 0)
 
 template <int GROUP>
-__device__ __forceinline__ mat<GROUP> link_line(const double2* __restrict__ U, const Geom& g, Site& q, int dir, int len)
+__device__ __forceinline__ mat<GROUP> link_line(const real2* __restrict__ U, const Geom& g, Site& q, int dir, int len)
 {
     mat<GROUP> m = load_site_link<GROUP>(U, g, dir, q);
     for (int k = 1; k < len; k++) {
@@ -1573,7 +1593,7 @@ __device__ __forceinline__ mat<GROUP> link_line(const double2* __restrict__ U, c
 }
 
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_wilson(const double2* __restrict__ U, const Geom g, const int R, const int T,
+__global__ __launch_bounds__(BLOCK) void k_wilson(const real2* __restrict__ U, const Geom g, const int R, const int T,
                                                   double2* __restrict__ partial)
 {
     double sum = 0.0;
@@ -1600,7 +1620,7 @@ __global__ __launch_bounds__(BLOCK) void k_wilson(const double2* __restrict__ U,
 // loops[y + Ny (z + Nz xs)] = P of that space site, for the profiles below.
 
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_polyakov(const double2* __restrict__ U, const Geom g,
+__global__ __launch_bounds__(BLOCK) void k_polyakov(const real2* __restrict__ U, const Geom g,
                                                     double2* __restrict__ partial, const int nblocks,
                                                     double2* __restrict__ loops)
 {
@@ -1672,7 +1692,7 @@ __device__ __forceinline__ cplx trace_gell_mann(const su2& p, int index)
 }
 
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_fmunu(const double2* __restrict__ U, const Geom g, const int field, const int index1,
+__global__ __launch_bounds__(BLOCK) void k_fmunu(const real2* __restrict__ U, const Geom g, const int field, const int index1,
                                                  const int index2, double2* __restrict__ partial, const int nblocks)
 {
     double f[12];
@@ -1777,7 +1797,7 @@ __global__ __launch_bounds__(BLOCK) void k_loops_profile(const double2* __restri
 // stand-alone re-unitarisation of every owned link (kernel lattice_GramSchmidt, suncl.cl:349-396)
 
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_reunit(double2* __restrict__ U, const Geom g)
+__global__ __launch_bounds__(BLOCK) void k_reunit(real2* __restrict__ U, const Geom g)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= 2 * g.vh_int) return;
@@ -1794,13 +1814,13 @@ __global__ __launch_bounds__(BLOCK) void k_reunit(double2* __restrict__ U, const
 
 // cold start: every stored link (halos included) = 1 (kernel lattice_init_cold, suncl.cl:163-187)
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_init_cold(double2* __restrict__ U, const Geom g)
+__global__ __launch_bounds__(BLOCK) void k_init_cold(real2* __restrict__ U, const Geom g)
 {
     const size_t n = (size_t)8 * ncomp<GROUP>::value * g.vh_alloc;
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
         const int c = (int)((i / g.vh_alloc) % ncomp<GROUP>::value);
         const bool diag = (GROUP == 3) ? (c == 0 || c == 4) : (c == 0);
-        U[i] = make_double2(diag ? 1.0 : 0.0, 0.0);
+        U[i] = make_real2(diag ? (real)1 : (real)0, (real)0);
     }
 }
 
@@ -1864,7 +1884,7 @@ __device__ __forceinline__ su2 hot_link(const float* r, int stride, su2*)
 }
 
 template <int GROUP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_init_hot(double2* __restrict__ U, const Geom g, const RlxView rv,
+__global__ __launch_bounds__(BLOCK) void k_init_hot(real2* __restrict__ U, const Geom g, const RlxView rv,
                                                     unsigned long long* __restrict__ draws)
 {
     __shared__ float rbuf[24 * BLOCK];
@@ -1946,7 +1966,7 @@ __global__ __launch_bounds__(BLOCK) void k_math_check(const double* __restrict__
 // rows of double4, element [lg + row*rowsize], lg = y + z*Ny + t*Ny*Nz + xl*Ny*Nz*Nt.
 
 template <int GROUP, bool TO_ENGINE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_convert(double2* __restrict__ U, const Geom g, double4* __restrict__ table,
+__global__ __launch_bounds__(BLOCK) void k_convert(real2* __restrict__ U, const Geom g, real4* __restrict__ table,
                                                    const int rowsize, const int slice0, const int nslices)
 {
     const int lg = blockIdx.x * BLOCK + threadIdx.x;
@@ -1964,37 +1984,37 @@ __global__ __launch_bounds__(BLOCK) void k_convert(double2* __restrict__ U, cons
 #pragma unroll
     for (int dir = 0; dir < 4; dir++) {
         if (GROUP == 3) {
-            double4* q0 = table + (size_t)(0 * 4 + dir) * rowsize + lg;
-            double4* q1 = table + (size_t)(1 * 4 + dir) * rowsize + lg;
-            double4* q2 = table + (size_t)(2 * 4 + dir) * rowsize + lg;
-            double2* p = U + comp_base<3>(g, dir, par) + h;
+            real4* q0 = table + (size_t)(0 * 4 + dir) * rowsize + lg;
+            real4* q1 = table + (size_t)(1 * 4 + dir) * rowsize + lg;
+            real4* q2 = table + (size_t)(2 * 4 + dir) * rowsize + lg;
+            real2* p = U + comp_base<3>(g, dir, par) + h;
             const size_t st = g.vh_alloc;
             if (TO_ENGINE) {
-                const double4 a = *q0, b = *q1, c = *q2;
-                p[0 * st] = make_double2(a.x, b.x);  // u1
-                p[1 * st] = make_double2(a.y, b.y);  // u2
-                p[2 * st] = make_double2(a.z, b.z);  // u3
-                p[3 * st] = make_double2(c.x, c.z);  // v1
-                p[4 * st] = make_double2(c.y, c.w);  // v2
-                p[5 * st] = make_double2(a.w, b.w);  // v3
+                const real4 a = *q0, b = *q1, c = *q2;
+                p[0 * st] = make_real2(a.x, b.x);  // u1
+                p[1 * st] = make_real2(a.y, b.y);  // u2
+                p[2 * st] = make_real2(a.z, b.z);  // u3
+                p[3 * st] = make_real2(c.x, c.z);  // v1
+                p[4 * st] = make_real2(c.y, c.w);  // v2
+                p[5 * st] = make_real2(a.w, b.w);  // v3
             } else {
-                const double2 u1 = p[0 * st], u2 = p[1 * st], u3 = p[2 * st];
-                const double2 v1 = p[3 * st], v2 = p[4 * st], v3 = p[5 * st];
-                *q0 = make_double4(u1.x, u2.x, u3.x, v3.x);
-                *q1 = make_double4(u1.y, u2.y, u3.y, v3.y);
-                *q2 = make_double4(v1.x, v2.x, v1.y, v2.y);
+                const real2 u1 = p[0 * st], u2 = p[1 * st], u3 = p[2 * st];
+                const real2 v1 = p[3 * st], v2 = p[4 * st], v3 = p[5 * st];
+                *q0 = make_real4(u1.x, u2.x, u3.x, v3.x);
+                *q1 = make_real4(u1.y, u2.y, u3.y, v3.y);
+                *q2 = make_real4(v1.x, v2.x, v1.y, v2.y);
             }
         } else {
-            double4* q0 = table + (size_t)dir * rowsize + lg;
-            double2* p = U + comp_base<2>(g, dir, par) + h;
+            real4* q0 = table + (size_t)dir * rowsize + lg;
+            real2* p = U + comp_base<2>(g, dir, par) + h;
             const size_t st = g.vh_alloc;
             if (TO_ENGINE) {
-                const double4 a = *q0;
-                p[0 * st] = make_double2(a.x, a.z);  // u1
-                p[1 * st] = make_double2(a.y, a.w);  // u2
+                const real4 a = *q0;
+                p[0 * st] = make_real2(a.x, a.z);  // u1
+                p[1 * st] = make_real2(a.y, a.w);  // u2
             } else {
-                const double2 u1 = p[0 * st], u2 = p[1 * st];
-                *q0 = make_double4(u1.x, u2.x, u1.y, u2.y);
+                const real2 u1 = p[0 * st], u2 = p[1 * st];
+                *q0 = make_real4(u1.x, u2.x, u1.y, u2.y);
             }
         }
     }
@@ -2002,15 +2022,15 @@ __global__ __launch_bounds__(BLOCK) void k_convert(double2* __restrict__ U, cons
 
 // boundary slice <-> message buffer: buf[c*slice_h + r]
 template <int GROUP, bool PACK, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_halo(double2* __restrict__ U, const Geom g, const int dir, const int par,
-                                                const int stored_slice, double2* __restrict__ buf)
+__global__ __launch_bounds__(BLOCK) void k_halo(real2* __restrict__ U, const Geom g, const int dir, const int par,
+                                                const int stored_slice, real2* __restrict__ buf)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     constexpr int NC = ncomp<GROUP>::value;
     if (i >= NC * g.slice_h) return;
     const int c = i / g.slice_h;
     const int r = i - c * g.slice_h;
-    double2* p = U + comp_base<GROUP>(g, dir, par) + (size_t)c * g.vh_alloc + (size_t)stored_slice * g.slice_h + r;
+    real2* p = U + comp_base<GROUP>(g, dir, par) + (size_t)c * g.vh_alloc + (size_t)stored_slice * g.slice_h + r;
     if (PACK) buf[i] = *p;
     else *p = buf[i];
 }

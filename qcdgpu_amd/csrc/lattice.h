@@ -9,7 +9,7 @@
 // Layout (differs from the reference's 4-vector rows on purpose): even/odd split,
 // component-major, one fp64 complex (16 B) per lane:
 //
-//     U[dir][parity][comp][h]      h in [0, vh_alloc),  comp in [0, NCOMP)
+//     U[dir][parity][comp][h]      h in [0, vh_alloc),  comp in [0, NCOMP)      (one complex number of the library's precision)
 //
 // NCOMP = 6 for SU(3) (rows u and v; w = (u x v)* is rebuilt in registers), 2 for SU(2)
 // (row u).  A wavefront reading component c of 64 consecutive half-sites moves 1 KiB with one
@@ -156,52 +156,84 @@ __host__ __device__ __forceinline__ size_t comp_base(const Geom& g, int dir, int
     return (size_t)((dir * 2 + par) * ncomp<GROUP>::value) * (size_t)g.vh_alloc;
 }
 
-__device__ __forceinline__ su3 load_link(const double2* __restrict__ U, const Geom& g, int dir,
+__device__ __forceinline__ su3 load_link(const real2* __restrict__ U, const Geom& g, int dir,
                                          int par, int h, su3*)
 {
-    const double2* p = U + comp_base<3>(g, dir, par) + h;
+    const real2* p = U + comp_base<3>(g, dir, par) + h;
     su3 m;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-        const double2 v = p[(size_t)c * g.vh_alloc];
+        const real2 v = p[(size_t)c * g.vh_alloc];
         m.e[c / 3][c % 3] = mk(v.x, v.y);
     }
     reconstruct(m);
     return m;
 }
-__device__ __forceinline__ su2 load_link(const double2* __restrict__ U, const Geom& g, int dir,
+__device__ __forceinline__ su2 load_link(const real2* __restrict__ U, const Geom& g, int dir,
                                          int par, int h, su2*)
 {
-    const double2* p = U + comp_base<2>(g, dir, par) + h;
+    const real2* p = U + comp_base<2>(g, dir, par) + h;
     su2 m;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        const double2 v = p[(size_t)c * g.vh_alloc];
+        const real2 v = p[(size_t)c * g.vh_alloc];
         m.e[0][c] = mk(v.x, v.y);
     }
     reconstruct(m);
     return m;
 }
 template <int GROUP>
-__device__ __forceinline__ mat<GROUP> load_site_link(const double2* __restrict__ U, const Geom& g,
+__device__ __forceinline__ mat<GROUP> load_site_link(const real2* __restrict__ U, const Geom& g,
                                                      int dir, const Site& s)
 {
     return load_link(U, g, dir, site_parity(g, s), half_index(g, s), (mat<GROUP>*)nullptr);
 }
 
-__device__ __forceinline__ void store_link(double2* __restrict__ U, const Geom& g, int dir, int par,
+__device__ __forceinline__ void store_link(real2* __restrict__ U, const Geom& g, int dir, int par,
                                            int h, const su3& m)
 {
-    double2* p = U + comp_base<3>(g, dir, par) + h;
+    real2* p = U + comp_base<3>(g, dir, par) + h;
 #pragma unroll
-    for (int c = 0; c < 6; c++) p[(size_t)c * g.vh_alloc] = make_double2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im);
+    for (int c = 0; c < 6; c++) p[(size_t)c * g.vh_alloc] = make_real2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im);
 }
-__device__ __forceinline__ void store_link(double2* __restrict__ U, const Geom& g, int dir, int par,
+__device__ __forceinline__ void store_link(real2* __restrict__ U, const Geom& g, int dir, int par,
                                            int h, const su2& m)
 {
-    double2* p = U + comp_base<2>(g, dir, par) + h;
+    real2* p = U + comp_base<2>(g, dir, par) + h;
 #pragma unroll
-    for (int c = 0; c < 2; c++) p[(size_t)c * g.vh_alloc] = make_double2(m.e[0][c].re, m.e[0][c].im);
+    for (int c = 0; c < 2; c++) p[(size_t)c * g.vh_alloc] = make_real2(m.e[0][c].re, m.e[0][c].im);
+}
+
+using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+using u32x2 = unsigned int __attribute__((ext_vector_type(2)));
+
+// one stored complex number per lane: 16 bytes (fp64) or 8 bytes (fp32); AUX = cache policy bits
+template <int AUX>
+__device__ __forceinline__ void buf_load_c(double2& v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_load_c(float2& v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, voffset, soffset, AUX));
+}
+template <int AUX = 0>
+__device__ __forceinline__ real2 buf_load_c(__amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    real2 v;
+    buf_load_c<AUX>(v, r, voffset, soffset);
+    return v;
+}
+template <int AUX = 0>
+__device__ __forceinline__ void buf_store_c(double2 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voffset, soffset, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void buf_store_c(float2 v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voffset, soffset, AUX);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,31 +242,29 @@ __device__ __forceinline__ void store_link(double2* __restrict__ U, const Geom& 
 // 32-bit vector offset and the component stride into the scalar offset, so a link costs one
 // integer add per lane instead of six 64-bit address computations.
 
-using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
-
 template <int GROUP>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc(const double2* U, const Geom& g, int dir, int par)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc(const real2* U, const Geom& g, int dir, int par)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(U + comp_base<GROUP>(g, dir, par)), 0,
-                                             ncomp<GROUP>::value * g.vh_alloc * 16, 0x00020000);
+                                             ncomp<GROUP>::value * g.vh_alloc * CB, 0x00020000);
 }
 
 // both parities of one direction behind one descriptor: the second parity's links start
 // ncomp * vh_alloc * 16 bytes behind the first's (for kernels whose waves hold sites of both)
 template <int GROUP>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc_both(const double2* U, const Geom& g, int dir)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t link_rsrc_both(const real2* U, const Geom& g, int dir)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(U + comp_base<GROUP>(g, dir, 0)), 0,
-                                             2 * ncomp<GROUP>::value * g.vh_alloc * 16, 0x00020000);
+                                             2 * ncomp<GROUP>::value * g.vh_alloc * CB, 0x00020000);
 }
 
-// byte_off = 16 * half index
+// byte_off = CB * half index
 __device__ __forceinline__ su3 load_link_buf(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off, su3*)
 {
     su3 m;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
-        const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, c * g.vh_alloc * 16, 0));
+        const real2 v = buf_load_c(r, byte_off, c * g.vh_alloc * CB);
         m.e[c / 3][c % 3] = mk(v.x, v.y);
     }
     reconstruct(m);
@@ -245,7 +275,7 @@ __device__ __forceinline__ su2 load_link_buf(__amdgpu_buffer_rsrc_t r, const Geo
     su2 m;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-        const double2 v = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, c * g.vh_alloc * 16, 0));
+        const real2 v = buf_load_c(r, byte_off, c * g.vh_alloc * CB);
         m.e[0][c] = mk(v.x, v.y);
     }
     reconstruct(m);
@@ -262,8 +292,7 @@ __device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const G
 {
 #pragma unroll
     for (int c = 0; c < 6; c++)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im)),
-                                               r, byte_off, c * g.vh_alloc * 16, AUX);
+        buf_store_c<AUX>(make_real2(m.e[c / 3][c % 3].re, m.e[c / 3][c % 3].im), r, byte_off, c * g.vh_alloc * CB);
 }
 // cache policy sc0 | sc1: the store is written through to memory, so that once the wavefront's
 // store count is back at zero a kernel that starts on any XCD reads the new value
@@ -272,8 +301,7 @@ __device__ __forceinline__ void store_link_buf(__amdgpu_buffer_rsrc_t r, const G
 {
 #pragma unroll
     for (int c = 0; c < 2; c++)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, make_double2(m.e[0][c].re, m.e[0][c].im)), r, byte_off,
-                                               c * g.vh_alloc * 16, QCD_STORE_AUX);
+        buf_store_c<QCD_STORE_AUX>(make_real2(m.e[0][c].re, m.e[0][c].im), r, byte_off, c * g.vh_alloc * CB);
 }
 
 // byte offsets from a site's half index to its eight nearest neighbours (periodic wrap
@@ -285,12 +313,12 @@ struct NbrOff {
 __device__ __forceinline__ NbrOff neighbour_offsets(const Geom& g, const Site& s)
 {
     NbrOff n;
-    const int sx = g.slice_h * 16, sz = g.nyh * 16, st = g.nyh * g.nz * 16;
+    const int sx = g.slice_h * CB, sz = g.nyh * CB, st = g.nyh * g.nz * CB;
     n.f0 = (!g.halo && s.xs == g.nx - 1) ? -(g.nx - 1) * sx : sx;
     n.b0 = (!g.halo && s.xs == 0) ? (g.nx - 1) * sx : -sx;
     const int yb = s.y & 1;
-    n.f1 = (s.y == g.ny - 1) ? -(g.nyh - 1) * 16 : (yb ? 16 : 0);
-    n.b1 = (s.y == 0) ? (g.nyh - 1) * 16 : (yb ? 0 : -16);
+    n.f1 = (s.y == g.ny - 1) ? -(g.nyh - 1) * CB : (yb ? CB : 0);
+    n.b1 = (s.y == 0) ? (g.nyh - 1) * CB : (yb ? 0 : -CB);
     n.f2 = (s.z == g.nz - 1) ? -(g.nz - 1) * sz : sz;
     n.b2 = (s.z == 0) ? (g.nz - 1) * sz : -sz;
     n.f3 = (s.t == g.nt - 1) ? -(g.nt - 1) * st : st;

@@ -1,7 +1,7 @@
 // su_math.h -- register-resident SU(2)/SU(3) algebra for the gfx950 kernels.
 //
-// Every matrix lives in VGPRs as fully unrolled, statically indexed arrays of fp64 complex
-// numbers; there is no MFMA here on purpose (3x3 contractions are far below one MFMA tile).
+// Every matrix lives in VGPRs as fully unrolled, statically indexed arrays of complex numbers
+// of the library's precision (`real`, fastmath.h); there is no MFMA here on purpose (3x3 contractions are far below one MFMA tile).
 // The term order inside each product follows the reference's sequential CPU path
 // (SU(N)/suncpp/su3/algebra_su3.cpp:118-143, su2/algebra_su2.cpp:90-102) so that, apart from
 // fused multiply-adds, the device rounds like the CPU checker does.
@@ -14,10 +14,10 @@
 namespace qcd {
 
 struct cplx {
-    double re, im;
+    real re, im;
 };
 
-__device__ __forceinline__ cplx mk(double re, double im)
+__device__ __forceinline__ cplx mk(real re, real im)
 {
     cplx c;
     c.re = re;
@@ -103,7 +103,7 @@ __device__ __forceinline__ mat<N> zero()
 #pragma unroll
     for (int i = 0; i < N; i++)
 #pragma unroll
-        for (int j = 0; j < N; j++) r.e[i][j] = mk(0.0, 0.0);
+        for (int j = 0; j < N; j++) r.e[i][j] = mk((real)0, (real)0);
     return r;
 }
 
@@ -112,7 +112,7 @@ __device__ __forceinline__ mat<N> unity()
 {
     mat<N> r = zero<N>();
 #pragma unroll
-    for (int i = 0; i < N; i++) r.e[i][i].re = 1.0;
+    for (int i = 0; i < N; i++) r.e[i][i].re = (real)1;
     return r;
 }
 
@@ -152,7 +152,7 @@ __device__ __forceinline__ void gram_schmidt(su3& a, const Math& m)
     cplx u1 = a.e[0][0], u2 = a.e[0][1], u3 = a.e[0][2];
     cplx v1 = a.e[1][0], v2 = a.e[1][1], v3 = a.e[1][2];
     // one reciprocal norm and six products instead of the reference's six quotients (<= 1 ulp apart)
-    double norm_u, iu;
+    real norm_u, iu;
     m.sqrt_rcp(u1.re * u1.re + u2.re * u2.re + u3.re * u3.re + u1.im * u1.im + u2.im * u2.im + u3.im * u3.im, norm_u, iu);
     u1 = mk(u1.re * iu, u1.im * iu);
     u2 = mk(u2.re * iu, u2.im * iu);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void gram_schmidt(su3& a, const Math& m)
     v1 = csub(v1, cmul(u1, sp));
     v2 = csub(v2, cmul(u2, sp));
     v3 = csub(v3, cmul(u3, sp));
-    double norm_v, iv;
+    real norm_v, iv;
     m.sqrt_rcp(v1.re * v1.re + v2.re * v2.re + v3.re * v3.re + v1.im * v1.im + v2.im * v2.im + v3.im * v3.im, norm_v, iv);
     v1 = mk(v1.re * iv, v1.im * iv);
     v2 = mk(v2.re * iv, v2.im * iv);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void gram_schmidt(su3& a) { gram_schmidt(a, MathLib()
 __device__ __forceinline__ void gram_schmidt(su2& a)
 {
     cplx u1 = a.e[0][0], u2 = a.e[0][1];
-    const double n = sqrt(u1.re * u1.re + u1.im * u1.im + u2.re * u2.re + u2.im * u2.im);
+    const real n = sqrt(u1.re * u1.re + u1.im * u1.im + u2.re * u2.re + u2.im * u2.im);
     a.e[0][0] = mk(u1.re / n, u1.im / n);
     a.e[0][1] = mk(u2.re / n, u2.im / n);
     reconstruct(a);
