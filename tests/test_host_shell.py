@@ -90,9 +90,11 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "qcdgpu_amd.h")).read()
     declared = set(re.findall(r"\b(qcd_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"qcd_ctx", "qcd_params", "qcd_timing"}
-    lib = C.CDLL(os.path.join(ROOT, "qcdgpu_amd", "lib", "libqcdgpu_amd.so"))
-    for name in sorted(declared):
-        assert hasattr(lib, name), name
+    for so in ("libqcdgpu_amd.so", "libqcdgpu_amd_f32.so"):      # the double and the single precision build
+        lib = C.CDLL(os.path.join(ROOT, "qcdgpu_amd", "lib", so))
+        for name in sorted(declared):
+            assert hasattr(lib, name), (so, name)
+        assert lib.qcd_precision() == (2 if so == "libqcdgpu_amd.so" else 1)
     from qcdgpu_amd import capi
     assert declared == set(capi.EXPORTS)
 
