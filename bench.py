@@ -340,6 +340,26 @@ def main():
                                  "limited_by": measured_traffic("on_limited_by")}}}
         except q.QcdError as e:
             log("O(N) leg skipped: %s" % e)
+        # the headline lattice in single precision (the reference's PRECISION switch; its paper quotes every
+        # timing in both precisions): the float build of the library, not part of `value`
+        try:
+            with q.Context(group=3, L=L, beta=args.beta, nhit=10, device=local_rank, precision=1) as c32:
+                c32.init_lattice()
+                c32.sweep(args.warmup)
+                f_ms, f_launches = c32.timed_sweeps(args.steps)
+                f_pass_s = f_ms * 1e-3 / f_launches
+                f_bytes = 432.0 * (n ** 4) / 2      # 8 links read + 1 written, 48 B each, per updated link
+                f_gbs = f_bytes / f_pass_s / 1e9
+                result.setdefault("other_workloads", {})["su3_%dx4_f32" % n] = {
+                    "link_updates_per_s": 4.0 * n ** 4 * args.steps / (f_ms * 1e-3), "ms_per_sweep": f_ms / args.steps,
+                    "workload": "SU(3) %d^4 heat-bath sweep in single precision (float links and arithmetic, fp64 sums), beta %.2f" % (n, args.beta),
+                    "mean_plaquette": float(c32.plaquette()[2]),
+                    "roofline": {"bound": "hbm", "achieved": f_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": f_gbs / HBM_PEAK_GBS, "kernel": "qcd_f32::k_update_gh", "avg_launch_us": 1e6 * f_pass_s,
+                                 "algorithmic_bytes_per_launch": f_bytes,
+                                 "traffic": measured_traffic("f32_hbm_bytes_per_update_launch")}}
+        except (q.QcdError, ImportError) as e:
+            log("single-precision leg skipped: %s" % e)
         log("CPU baseline leg (bounded sample, one core)")
         result["cpu_baseline"] = cpu_baseline(log)
     else:

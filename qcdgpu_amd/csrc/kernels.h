@@ -1475,6 +1475,9 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const real2* __restrict__ U
 // Threads: (y, z, t) cross-section in storage order times Nx / XSEG segments; same partial /
 // site_vals outputs.  (Workgroups shaped as tiles in (z, t) instead of rows in storage order, and
 // workgroups of 512, were measured as well: 144 and 151 us per call against 141.)
+// The kernel needs 257 registers in double precision, so a SIMD holds one wavefront and the 2048 of a 32^4 call
+// run in two rounds; capped at 256 (two wavefronts per SIMD, all resident) it takes the same 140 us with 7.4 M
+// L2 misses instead of 5.6 M: twice the columns in flight ask for twice the lines per step.
 template <int BLOCK, int XSEG>
 __global__ __launch_bounds__(BLOCK) void k_plaquette_march(const real2* __restrict__ U, const Geom g,
                                                            double2* __restrict__ partial, double2* __restrict__ site_vals)

@@ -27,9 +27,27 @@ __device__ __forceinline__ cplx mk(real re, real im)
 __device__ __forceinline__ cplx conj(cplx a) { return mk(a.re, -a.im); }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return mk(a.re + b.re, a.im + b.im); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return mk(a.re - b.re, a.im - b.im); }
+// Single precision: complex products as packed pairs.  c += a * b is two v_pk_fma_f32 on (re, im) register
+// pairs -- (a.re, a.re) * (b.re, b.im) + c, then (-a.im, a.im) * (b.im, b.re) + that -- against four scalar
+// multiply-adds; the instruction selector folds the swaps into the operand selects of the packed form.  The
+// float build is bound by instruction issue, not by memory (fastmath.h has the precision switch).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk(cplx a) { return (v2f){(float)a.re, (float)a.im}; }
+__device__ __forceinline__ cplx unpk(v2f a) { return mk((real)a.x, (real)a.y); }
+__device__ __forceinline__ v2f pk_cmac(v2f c, v2f a, v2f b)
+{
+    c = __builtin_elementwise_fma(a.xx, b, c);
+    return __builtin_elementwise_fma((v2f){-a.y, a.y}, b.yx, c);
+}
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b)
+{
+    return __builtin_elementwise_fma((v2f){-a.y, a.y}, b.yx, a.xx * b);
+}
+
 // SU(N)/kernel/complex.h:371-376
 __device__ __forceinline__ cplx cmul(cplx a, cplx b)
 {
+    if constexpr (!REAL_IS_DOUBLE) return unpk(pk_cmul(pk(a), pk(b)));
     return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
 }
 
@@ -43,6 +61,7 @@ using su2 = mat<2>;
 // one entry of a product: sum_k a_k * b_k, in the reference's term order
 __device__ __forceinline__ cplx dot3(cplx a1, cplx a2, cplx a3, cplx b1, cplx b2, cplx b3)
 {
+    if constexpr (!REAL_IS_DOUBLE) return unpk(pk_cmac(pk_cmac(pk_cmul(pk(a1), pk(b1)), pk(a2), pk(b2)), pk(a3), pk(b3)));
     cplx c;
     c.re = -a1.im * b1.im + a1.re * b1.re - a2.im * b2.im + a2.re * b2.re - a3.im * b3.im + a3.re * b3.re;
     c.im = a1.re * b1.im + a1.im * b1.re + a2.re * b2.im + a2.im * b2.re + a3.re * b3.im + a3.im * b3.re;
@@ -50,6 +69,7 @@ __device__ __forceinline__ cplx dot3(cplx a1, cplx a2, cplx a3, cplx b1, cplx b2
 }
 __device__ __forceinline__ cplx dot2(cplx a1, cplx a2, cplx b1, cplx b2)
 {
+    if constexpr (!REAL_IS_DOUBLE) return unpk(pk_cmac(pk_cmul(pk(a1), pk(b1)), pk(a2), pk(b2)));
     cplx c;
     c.re = -a1.im * b1.im + a1.re * b1.re - a2.im * b2.im + a2.re * b2.re;
     c.im = a1.re * b1.im + a1.im * b1.re + a2.re * b2.im + a2.im * b2.re;
@@ -130,6 +150,15 @@ __device__ __forceinline__ void reconstruct(su3& a)
 {
     const cplx u1 = a.e[0][0], u2 = a.e[0][1], u3 = a.e[0][2];
     const cplx v1 = a.e[1][0], v2 = a.e[1][1], v3 = a.e[1][2];
+    if constexpr (!REAL_IS_DOUBLE) {
+        // w = conj(u x v): w1 = conj(u2 v3 - u3 v2), ...
+        const v2f p1 = pk(u1), p2 = pk(u2), p3 = pk(u3), q1 = pk(v1), q2 = pk(v2), q3 = pk(v3);
+        const v2f w1 = pk_cmac(pk_cmul(p2, q3), -p3, q2), w2 = pk_cmac(pk_cmul(p3, q1), -p1, q3), w3 = pk_cmac(pk_cmul(p1, q2), -p2, q1);
+        a.e[2][0] = mk((real)w1.x, (real)-w1.y);
+        a.e[2][1] = mk((real)w2.x, (real)-w2.y);
+        a.e[2][2] = mk((real)w3.x, (real)-w3.y);
+        return;
+    }
     a.e[2][0].re = u3.im * v2.im - u3.re * v2.re - u2.im * v3.im + u2.re * v3.re;
     a.e[2][0].im = u3.re * v2.im + u3.im * v2.re - u2.re * v3.im - u2.im * v3.re;
     a.e[2][1].re = -u3.im * v1.im + u3.re * v1.re + u1.im * v3.im - u1.re * v3.re;

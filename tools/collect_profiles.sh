@@ -16,5 +16,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
       python3 "$ROOT/tools/calib_reunit.py" > "$OUT/calib_$c.log" 2>&1 || { echo "calib $c failed"; exit 1; }
 done
 bash "$ROOT/tools/profile_on.sh" "$OUT/on" || exit 1
+bash "$ROOT/tools/profile_f32.sh" "$OUT/f32" || exit 1
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/calib_FETCH_SIZE" > "$OUT/calib_fetch.json" &&
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/calib_WRITE_SIZE" > "$OUT/calib_write.json" && echo "calib ok"

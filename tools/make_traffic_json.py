@@ -11,17 +11,17 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
-per = {}
+per, per32 = {}, {}
 for k, v in pmc.items():
     if "k_update" in k and "redo" not in k:
-        per[k] = {"fetch_bytes": 2 * 1024.0 * v["FETCH_SIZE"]["mean_per_dispatch"],
-                  "write_bytes": 1024.0 * v["WRITE_SIZE"]["mean_per_dispatch"]}
+        (per32 if "qcd_f32::" in k else per)[k] = {"fetch_bytes": 2 * 1024.0 * v["FETCH_SIZE"]["mean_per_dispatch"],
+                                                   "write_bytes": 1024.0 * v["WRITE_SIZE"]["mean_per_dispatch"]}
 fetch = sum(p["fetch_bytes"] for p in per.values()) / len(per)
 write = sum(p["write_bytes"] for p in per.values()) / len(per)
 cal_f = json.load(open(os.path.join(src, "calib_fetch.json")))
 cal_w = json.load(open(os.path.join(src, "calib_write.json")))
-kf = [v for k, v in cal_f.items() if "k_reunit" in k][0]["FETCH_SIZE"]["mean_per_dispatch"]
-kw = [v for k, v in cal_w.items() if "k_reunit" in k][0]["WRITE_SIZE"]["mean_per_dispatch"]
+kf = [v for k, v in cal_f.items() if "qcd::k_reunit" in k][0]["FETCH_SIZE"]["mean_per_dispatch"]
+kw = [v for k, v in cal_w.items() if "qcd::k_reunit" in k][0]["WRITE_SIZE"]["mean_per_dispatch"]
 true_bytes = 402653184.0
 out = {
     "hbm_bytes_per_update_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "per_kernel": per,
@@ -33,6 +33,29 @@ out = {
                     "fetch_ratio_reported_over_true": 1024.0 * kf / true_bytes,
                     "write_ratio_reported_over_true": 1024.0 * kw / true_bytes},
 }
+# the single-precision library's update pass, when tools/profile_f32.sh ran into <src>/f32
+f32_dir = os.path.join(src, "f32")
+if os.path.exists(os.path.join(f32_dir, "fetch.json")):
+    f = json.load(open(os.path.join(f32_dir, "fetch.json")))
+    w = json.load(open(os.path.join(f32_dir, "write.json")))
+    keys = [k for k in f if "qcd_f32::k_update_gh" in k]
+    fb = sum(2 * 1024.0 * f[k]["FETCH_SIZE"]["mean_per_dispatch"] for k in keys) / len(keys)
+    wb = sum(1024.0 * w[k]["WRITE_SIZE"]["mean_per_dispatch"] for k in keys) / len(keys)
+    out["f32_hbm_bytes_per_update_launch"] = fb + wb
+    out["f32_fetch_bytes"], out["f32_write_bytes"] = fb, wb
+    kf32 = [v for k, v in cal_f.items() if "qcd_f32::k_reunit" in k]
+    kw32 = [v for k, v in cal_w.items() if "qcd_f32::k_reunit" in k]
+    if kf32 and kw32:
+        out["f32_calibration"] = {"kernel": "qcd_f32::k_reunit 32^4 SU(3): reads %d B and writes %d B per launch (8 B per lane)" % (true_bytes / 2, true_bytes / 2),
+                                  "fetch_ratio_reported_over_true": 1024.0 * kf32[0]["FETCH_SIZE"]["mean_per_dispatch"] / (true_bytes / 2),
+                                  "write_ratio_reported_over_true": 1024.0 * kw32[0]["WRITE_SIZE"]["mean_per_dispatch"] / (true_bytes / 2)}
+    os.makedirs(dst, exist_ok=True)
+    for name in ("fetch", "write", "insts", "cache"):
+        if os.path.exists(os.path.join(f32_dir, name + ".json")):
+            shutil.copy(os.path.join(f32_dir, name + ".json"), os.path.join(dst, "f32_pmc_%s.json" % name))
+    for fn in os.listdir(os.path.join(f32_dir, "trace")):
+        if fn.endswith("kernel_stats.csv"):
+            shutil.copy(os.path.join(f32_dir, "trace", fn), os.path.join(dst, "f32_kernel_stats.csv"))
 # the O(N) update pass, when tools/profile_on.sh ran into <src>/on
 on_dir = os.path.join(src, "on")
 if os.path.exists(os.path.join(on_dir, "fetch.json")):
