@@ -184,11 +184,12 @@ int qcd_measure_polyakov_profile_sums(qcd_ctx *ctx, int axis, double *sums);
 int qcd_measure_wilson(qcd_ctx *ctx, int R, int T, double *out);
 
 /* buffer_map / COPY_HOST_PTR of lattice_table (suncl.cpp:5498-5504, 3877-3991): the link table
- * of this context's slab in the REFERENCE device layout, double precision: rows of double4,
+ * of this context's slab in the REFERENCE device layout and the library's precision (qcd_precision): rows of
+ * double4, or of float4 in the single-precision build (hgpu_float4, SU(N)/suncl/model.cl:140-162),
  * element [gindex + row*rowsize], gindex = y + z*Ny + t*Ny*Nz + x_local*Ny*Nz*Nt;
  * SU(3): 12 rows, row = quad*4 + dir, quads (Re u1,Re u2,Re u3,Re v3), (Im u1,Im u2,Im u3,Im v3),
  * (Re v1,Re v2,Im v1,Im v2) (SU(N)/suncl/su3_matrix_memory.cl:42-176); SU(2): 4 rows, row = dir,
- * (Re u1,Re u2,Im u1,Im u2) (su2_matrix_memory.cl:55-142).  bytes = rows*rowsize*32. */
+ * (Re u1,Re u2,Im u1,Im u2) (su2_matrix_memory.cl:55-142).  bytes = rows*rowsize*32 (double), rows*rowsize*16 (single). */
 int qcd_upload(qcd_ctx *ctx, const void *host_table, size_t bytes, int rowsize);
 int qcd_download(qcd_ctx *ctx, void *host_table, size_t bytes, int rowsize);
 
