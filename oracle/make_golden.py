@@ -48,6 +48,15 @@ CASES = {
                                   PRNG="RANLUX2", RANDSERIES=99, NAV=1, ITER=4, NITER=2),
     "su2_16x16x16x16_gid": dict(GROUP=2, ND=4, LS=16, LT=16, BETA=2.5, NHIT=10, INTS=2,
                                 PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=3, NITER=1),
+    # odd extents (the reference needs only L2 even): the sequential order decides which links a site sees updated
+    "su3_5x4x3x7_gid": dict(GROUP=3, ND=4, L1=5, L2=4, L3=3, L4=7, BETA=5.7, NHIT=4, INTS=2,
+                            PRNG="RANLUX3", RANDSERIES=7, NAV=1, ITER=3, NITER=2),
+    "su2_4x6x4x5_gid": dict(GROUP=2, ND=4, L1=4, L2=6, L3=4, L4=5, BETA=2.3, NHIT=5, INTS=2,
+                            PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=4, NITER=1),
+    "su3_3x2x3x3_gid": dict(GROUP=3, ND=4, L1=3, L2=2, L3=3, L4=3, BETA=6.0, NHIT=10, INTS=2,
+                            PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=4, NITER=1),
+    "su3_4x4x4x7_cold_rl3": dict(GROUP=3, ND=4, L1=4, L2=4, L3=4, L4=7, BETA=6.0, NHIT=10, INTS=1,
+                                 PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=3, NITER=1),
     "su3_8x8x8x8_cold_rl4_lowbeta": dict(GROUP=3, ND=4, LS=8, LT=8, BETA=1.5, NHIT=2, INTS=1,
                                          PRNG="RANLUX4", RANDSERIES=4321, NAV=0, ITER=3,
                                          NITER=1),

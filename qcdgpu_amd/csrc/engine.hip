@@ -205,6 +205,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
+    a.phase = -1;
     a.edge_local = 0;
     a.edge_total = 0u;
     a.edge_seq = 0u;
@@ -213,6 +214,25 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     const int edge_slices = c->edge_sig.slices;
     c->edge_sig.slices = 0;
     bool paired = false;   // launched as the gather / heat-bath pair kernel
+    if (g.odd) {
+        // phases by the number of odd directions in which a site sits at the far end (update_phase): at most three
+        if (edge_slices > 0 || xs_count != g.nx) return fail(QCD_ERR_UNSUPPORTED, "lattices with an odd extent are updated in whole passes");
+        const int nph = 1 + ((g.odd & 1) && dir != 0) + ((g.odd & 4) && dir != 2) + ((g.odd & 8) && dir != 3);
+        for (a.phase = 0; a.phase < nph; a.phase++) {
+#define QCD_LAUNCH_ANY(D) hipLaunchKernelGGL((k_update<GROUP, D, GID, (GID ? 0 : NSKIP), UPD_BLOCK, true>), grid, block, 0, stream, a)
+            switch (dir) {
+                case 0: QCD_LAUNCH_ANY(0); break;
+                case 1: QCD_LAUNCH_ANY(1); break;
+                case 2: QCD_LAUNCH_ANY(2); break;
+                default: QCD_LAUNCH_ANY(3); break;
+            }
+#undef QCD_LAUNCH_ANY
+        }
+        HIP_TRY(hipGetLastError());
+        if (!GID)
+            for (int k = 0; k < xs_count; k++) c->slice_slot[(xs_begin + k) % g.nx] ^= 1;
+        return QCD_OK;
+    }
     if constexpr (GROUP == 3 && !GID && UPD_BLOCK == 64) {
         // it has no code for partly filled blocks
         const bool full = ((long)g.unx * g.region_h) % UPD_BLOCK == 0 && g.tz == 0;
@@ -264,11 +284,21 @@ int launch_overrelax(qcd_ctx* c, int parity, int dir)
 {
     const Geom& g = c->g;
     const dim3 grid(g.nzr * g.ntr * cdiv((long)g.nx * g.region_h, UPD_BLOCK)), block(UPD_BLOCK);
+    if (g.odd) {
+        const int nph = 1 + ((g.odd & 1) && dir != 0) + ((g.odd & 4) && dir != 2) + ((g.odd & 8) && dir != 3);
+        for (int ph = 0; ph < nph; ph++) switch (dir) {
+            case 0: hipLaunchKernelGGL((k_overrelax<GROUP, 0, UPD_BLOCK, true>), grid, block, 0, c->stream, c->U, g, parity, ph); break;
+            case 1: hipLaunchKernelGGL((k_overrelax<GROUP, 1, UPD_BLOCK, true>), grid, block, 0, c->stream, c->U, g, parity, ph); break;
+            case 2: hipLaunchKernelGGL((k_overrelax<GROUP, 2, UPD_BLOCK, true>), grid, block, 0, c->stream, c->U, g, parity, ph); break;
+            default: hipLaunchKernelGGL((k_overrelax<GROUP, 3, UPD_BLOCK, true>), grid, block, 0, c->stream, c->U, g, parity, ph); break;
+        }
+        return QCD_OK;
+    }
     switch (dir) {
-        case 0: hipLaunchKernelGGL((k_overrelax<GROUP, 0, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
-        case 1: hipLaunchKernelGGL((k_overrelax<GROUP, 1, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
-        case 2: hipLaunchKernelGGL((k_overrelax<GROUP, 2, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
-        default: hipLaunchKernelGGL((k_overrelax<GROUP, 3, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity); break;
+        case 0: hipLaunchKernelGGL((k_overrelax<GROUP, 0, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, -1); break;
+        case 1: hipLaunchKernelGGL((k_overrelax<GROUP, 1, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, -1); break;
+        case 2: hipLaunchKernelGGL((k_overrelax<GROUP, 2, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, -1); break;
+        default: hipLaunchKernelGGL((k_overrelax<GROUP, 3, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, -1); break;
     }
     return QCD_OK;
 }
@@ -490,10 +520,12 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     for (int i = 0; i < 4; i++)
         if (p->L[i] < 2) return fail(QCD_ERR_INVALID, "lattice extent L[%d] = %d < 2", i, p->L[i]);
     if (p->L[1] & 1) return fail(QCD_ERR_INVALID, "Ny = %d must be even (checkerboard pairs sites 2h, 2h+1)", p->L[1]);
-    // links are stored by parity and a neighbour is looked up in the other parity's array: across
-    // the periodic wrap of an odd extent the neighbour has the SAME parity
-    if ((p->L[0] | p->L[2] | p->L[3]) & 1)
-        return fail(QCD_ERR_UNSUPPORTED, "odd lattice extents are not supported (%d x %d x %d x %d): the checkerboard does not close", p->L[0],
+    // Odd Nx, Nz or Nt (the reference needs only Ny even, SU(N)/suncpp/coord_work/coord_work.cpp:151-175): across the
+    // periodic wrap of an odd extent a site's neighbour has the SAME parity.  One context that owns the whole lattice
+    // serves this with kernels that look every neighbour's parity up and with passes run in phases (update_phase in
+    // kernels.h); a slab with halos does not (the wrap neighbour lives in another context, inside the same pass)
+    if (((p->L[0] | p->L[2] | p->L[3]) & 1) && p->halo)
+        return fail(QCD_ERR_UNSUPPORTED, "odd lattice extents (%d x %d x %d x %d) are supported for one uncut lattice only, not for x-slabs", p->L[0],
                     p->L[1], p->L[2], p->L[3]);
     if (p->nhit < 1) return fail(QCD_ERR_INVALID, "NHIT = %d < 1", p->nhit);
     if (p->lux_level < 0 || p->lux_level > 4) return fail(QCD_ERR_INVALID, "RANLUX level %d not in 0..4", p->lux_level);
@@ -537,6 +569,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     g.vh_alloc = (g.nx + 2 * g.halo) * g.slice_h;
     g.gsites = (int)sites;
     g.gslice = g.ny * g.nz * g.nt;
+    g.odd = (p->L[0] & 1) | ((p->L[2] & 1) << 2) | ((p->L[3] & 1) << 3);
     // (z,t) regions for the 8 XCDs: the split with the smallest cut surface that divides both
     // extents; none -> one region (plain linear order)
     g.nzr = g.ntr = 1;
@@ -883,7 +916,7 @@ static int launch_plaquette_into(qcd_ctx* c, double2* partial, double2* site_val
         // x segments per thread: long enough that the links carried along x pay, short enough for the grid to fill the device
         static const int seg_env = getenv("QCDGPU_AMD_PLAQ_XSEG") ? atoi(getenv("QCDGPU_AMD_PLAQ_XSEG")) : 0;   // diagnostic override (1: one site per thread)
         const Geom& g = c->g;
-        const int xseg = seg_env ? seg_env : ((long)g.gslice * cdiv(g.nx, 8) >= 256L * MEAS_BLOCK ? 8 : 4);
+        const int xseg = g.odd ? 1 : (seg_env ? seg_env : ((long)g.gslice * cdiv(g.nx, 8) >= 256L * MEAS_BLOCK ? 8 : 4));
         if (xseg != 8 && xseg != 4) {
             hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), dim3(c->npartial), block, 0, c->stream, c->U, c->g, partial, site_vals);
             *nparts = c->npartial;

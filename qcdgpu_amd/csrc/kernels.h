@@ -585,6 +585,48 @@ __device__ __forceinline__ mat<GROUP> staple(const real2* __restrict__ U, const 
     return stap;
 }
 
+// The same staple sum for lattices with an odd extent: every neighbour's parity is looked up from its own
+// coordinates (across the wrap of an odd direction it is the site's own parity), plain loads.
+template <int GROUP, int DIR>
+__device__ __forceinline__ mat<GROUP> staple_any(const real2* __restrict__ U, const Geom& g, const Site& x)
+{
+    using M = mat<GROUP>;
+    M stap = zero<GROUP>();
+    const Site xmu = fwd(g, x, DIR);
+#pragma unroll
+    for (int nu = 0; nu < 4; nu++) {
+        if (nu == DIR) continue;
+        {
+            const M m1 = load_site_link<GROUP>(U, g, nu, xmu);
+            const M m2 = herm(load_site_link<GROUP>(U, g, DIR, fwd(g, x, nu)));
+            const M m3 = herm(load_site_link<GROUP>(U, g, nu, x));
+            add_to(stap, mul(mul(m1, m2), m3));
+        }
+        {
+            const Site xb = bwd(g, x, nu);
+            const M m1 = herm(load_site_link<GROUP>(U, g, nu, fwd(g, xb, DIR)));
+            const M m2 = herm(load_site_link<GROUP>(U, g, DIR, xb));
+            const M m3 = load_site_link<GROUP>(U, g, nu, xb);
+            add_to(stap, mul(mul(m1, m2), m3));
+        }
+    }
+    return stap;
+}
+// Phase of a site in a pass over the links of direction `dir` on a lattice with odd extents.  Across the wrap of
+// an odd direction nu the staple of x reads U_dir(x +- nu) on a site of x's own parity, which the same pass
+// updates.  The reference's sequential program (SU(N)/suncpp/Update/sun_update.h:79-117) visits the sites in
+// index order, so the site at coordinate N_nu - 1 reads the NEW link of the site at 0 and that one the OLD link
+// of the site at N_nu - 1.  Sites are therefore updated in phases by the number of odd directions nu != dir in which
+// they sit at N_nu - 1: every same-parity link a site reads belongs to the phase before (new) or after (old) its own.
+__device__ __forceinline__ int update_phase(const Geom& g, const Site& x, int dir)
+{
+    int k = 0;
+    if (dir != 0 && (g.odd & 1) && x.xs == g.nx - 1) k++;
+    if (dir != 2 && (g.odd & 4) && x.z == g.nz - 1) k++;
+    if (dir != 3 && (g.odd & 8) && x.t == g.nt - 1) k++;
+    return k;
+}
+
 // SU(3) staple sum, software-pipelined and with a small register footprint.  Every staple term
 // is itself an SU(3) matrix, so only its first two rows are formed by products (from two rows of
 // the leading factor and the full other factor) and the third row is (row0 x row1)*, the rule the
@@ -898,6 +940,7 @@ struct UpdArgs {
     const float* gidr;
     unsigned long long* draws;
     int nblocks;   // blocks of BLOCK sites in the pass; workgroup b takes b, b + gridDim.x, ...
+    int phase;     // lattices with an odd extent: only the sites of this phase are updated (update_phase); else -1
     // Edge signal of a slab pass (edge_local = 0: none).  The first edge_local blocks of every
     // region are the slices next to the slab's two faces (the launch starts there); when the last
     // of them is stored and visible to the device, edge_seq is written to *edge_flag, on which
@@ -927,7 +970,8 @@ __device__ __forceinline__ void edge_block_done(const UpdArgs& a, const int lane
     }
 }
 
-template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK>
+// ANY: a lattice with an odd extent (staple_any, phases)
+template <int GROUP, int DIR, bool GID, int NSKIP, int BLOCK, bool ANY = false>
 __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs args_by_value)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs the signature only
@@ -953,7 +997,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     g.vh_int = ap->g.vh_int; g.vh_alloc = ap->g.vh_alloc; g.gsites = ap->g.gsites; g.gslice = ap->g.gslice;
     g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h;
     g.tz = ap->g.tz; g.tt = ap->g.tt; g.tx = ap->g.tx;
-    g.ux0 = ap->g.ux0; g.unx = ap->g.unx;
+    g.ux0 = ap->g.ux0; g.unx = ap->g.unx; g.odd = ap->g.odd;
     const int parity = ap->parity;
     const int nhit = ap->nhit;
     const real beta_eff = (real)ap->beta_eff;
@@ -963,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     const float* __restrict__ gidr = ap->gidr;
     Site x;
     int t;  // stream number = the site pair's half index in the slab
-    if (site_of_workgroup<BLOCK>(g, wb, threadIdx.x, parity, x, t)) {
+    if (site_of_workgroup<BLOCK>(g, wb, threadIdx.x, parity, x, t) && (!ANY || update_phase(g, x, DIR) == ap->phase)) {
         const int hb = half_index(g, x) * CB;
 #ifdef QCD_ABL_LOCAL  // diagnostic build: every neighbour is the site itself (minimal traffic, wrong physics)
         NbrOff nbr;
@@ -982,7 +1026,11 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
         }
 #endif
         mat<GROUP> A, Ul;
-        if constexpr (GROUP == 3) {
+        if constexpr (ANY) {
+            A = staple_any<GROUP, DIR>(U, g, x);
+            Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
+            if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
+        } else if constexpr (GROUP == 3) {
             // the stream's state is requested as soon as the staple's registers are free (requesting
             // state and link under the last staple term costs 40 registers and gains nothing)
             if (!GID) rs.attach(rv, t, rbuf + threadIdx.x);
@@ -1286,19 +1334,22 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
 
 // overrelaxation pass over the links of direction DIR on the sites of one parity: same gather
 // as the heat-bath pass, no random numbers
-template <int GROUP, int DIR, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 2) void k_overrelax(real2* __restrict__ U, const Geom g, const int parity)
+template <int GROUP, int DIR, int BLOCK, bool ANY = false>
+__global__ __launch_bounds__(BLOCK, 2) void k_overrelax(real2* __restrict__ U, const Geom g, const int parity, const int phase)
 {
     Site x;
     int t;
     if (!site_of_workgroup<BLOCK>(g, blockIdx.x, threadIdx.x, parity, x, t)) return;
+    if (ANY && update_phase(g, x, DIR) != phase) return;
     const int hb = half_index(g, x) * CB;
     const NbrOff nbr = neighbour_offsets(g, x);
     const __amdgpu_buffer_rsrc_t r_own = link_rsrc<GROUP>(U, g, DIR, parity);
     MathFast fm;
     fm.tab = nullptr;   // no logarithm on this path
     mat<GROUP> A;
-    if constexpr (GROUP == 3) {
+    if constexpr (ANY) {
+        A = staple_any<GROUP, DIR>(U, g, x);
+    } else if constexpr (GROUP == 3) {
         StaplePipe sp;
         staple_pipe_head<DIR>(sp, U, g, hb, nbr, parity);
         staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, NoHook());
@@ -1435,7 +1486,7 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const real2* __restrict__ U
     Site x;
     if (measurement_site<BLOCK>(g, x)) {
         const int par = site_parity(g, x);
-        if constexpr (GROUP == 3) {
+        if (GROUP == 3 && !g.odd) {
             const unsigned hb = (unsigned)half_index(g, x) * (unsigned)CB;
             const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * (unsigned)CB;
             const unsigned own_off = (par ? pbytes : 0u) + hb, other_off = (par ? 0u : pbytes) + hb;

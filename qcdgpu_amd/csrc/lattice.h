@@ -48,6 +48,10 @@ struct Geom {
     // the owned range (ux0 = 0, unx = nx: the whole slab).  Lets a slab update its boundary
     // slices first, so that their halo messages travel while the interior is updated.
     int ux0, unx;
+    // bit d set: the extent in direction d (0 x, 2 z, 3 t; y is always even) is odd.  Across the periodic wrap of
+    // such a direction a site's neighbour has the SAME parity; only the kernels that look a neighbour's parity
+    // up per site (load_site_link) serve such a lattice, and a checkerboard pass runs in phases (update_phase)
+    int odd;
 };
 
 struct Site {

@@ -69,7 +69,8 @@ def test_cold_start_known_answers(group):
         assert t.dtype == np.float32
 
 
-@pytest.mark.parametrize("group,L", [(3, (8, 8, 8, 8)), (2, (8, 8, 8, 8)), (3, (4, 6, 8, 4)), (2, (6, 4, 2, 8)), (3, (2, 34, 4, 4))])
+@pytest.mark.parametrize("group,L", [(3, (8, 8, 8, 8)), (2, (8, 8, 8, 8)), (3, (4, 6, 8, 4)), (2, (6, 4, 2, 8)), (3, (2, 34, 4, 4)),
+                                     (3, (5, 4, 3, 4))])   # the last one: odd extents, passes in phases
 def test_gid_mode_follows_the_fp64_checker(group, L):
     """Closed-form start and closed-form 'random' numbers: float links are the rounded double links, and
     two sweeps later plaquettes and links are still those of the fp64 checker to float rounding."""

@@ -41,7 +41,7 @@ def _run(tmp_path, keys, extra="", args=()):
     return text, fields, np.array(rows), r.stdout
 
 
-@pytest.mark.parametrize("case", ["ref_su3_8x8x8x8_gid.json", "ref_su2_6x8x4x10_gid.json"])
+@pytest.mark.parametrize("case", ["ref_su3_8x8x8x8_gid.json", "ref_su2_6x8x4x10_gid.json", "ref_su3_5x4x3x7_gid.json"])
 def test_cli_reproduces_reference_result_table(tmp_path, case):
     fx = ol.golden(case)
     text, fields, rows, _ = _run(tmp_path, fx["init"])

@@ -61,11 +61,12 @@ def test_gid_start_links_bit_exact_and_layout_roundtrip(group):
     lat.close()
 
 
-@pytest.mark.parametrize("group", [2, 3])
-def test_every_pass_matches_checker_link_by_link(group):
+@pytest.mark.parametrize("group,L", [(2, (4, 4, 6, 4)), (3, (4, 4, 6, 4)),
+                                     # odd extents: a pass runs in phases that reproduce the sequential order across the wrap
+                                     (2, (5, 4, 3, 7)), (3, (5, 4, 3, 7)), (3, (4, 2, 4, 3)), (3, (3, 2, 3, 3))])
+def test_every_pass_matches_checker_link_by_link(group, L):
     """gid mode, one (parity, direction) pass at a time: every link against the checker."""
     import qcdgpu_amd as q
-    L = (4, 4, 6, 4)
     beta = 6.0 if group == 3 else 2.4
     lat = ol.Lattice(group, L, beta, nhit=10, ints=2, rng_mode=ol.RNG_GID)
     with _ctx(group=group, L=L, beta=beta, nhit=10, start_mode=q.START_GID) as c:
@@ -113,6 +114,9 @@ def test_gid_runs_match_reference_vectors(case):
     (2, (6, 8, 4, 10), 1.2, 2, 2, 7),
     (3, (4, 4, 4, 6), 1.0, 12, 3, 5),      # more than 48 numbers per link for many links: the redo pass
     (2, (4, 4, 6, 4), 0.5, 14, 1, 8),      # the same for SU(2)
+    (3, (5, 4, 4, 7), 5.5, 10, 3, 54),     # odd Nx and Nt
+    (2, (4, 6, 3, 4), 2.3, 5, 2, 11),      # odd Nz
+    (3, (3, 4, 5, 3), 3.0, 3, 3, 3),       # all three odd, rejected trials
 ])
 def test_ranlux_runs_match_checker(group, L, beta, nhit, lux, seed):
     """Production RNG mode: one RANLUX stream per thread.  Same streams on both sides, so the
@@ -179,7 +183,7 @@ def test_heatbath_math_is_accurate_to_the_last_places():
 
 
 @pytest.mark.parametrize("group,L", [(3, (2, 2, 2, 2)), (3, (2, 6, 2, 2)), (3, (6, 10, 2, 4)), (3, (4, 34, 4, 4)),
-                                     (2, (2, 2, 2, 2)), (2, (10, 6, 6, 2))])
+                                     (2, (2, 2, 2, 2)), (2, (10, 6, 6, 2)), (3, (3, 2, 3, 3)), (2, (3, 2, 5, 3)), (3, (7, 18, 4, 5))])
 def test_small_and_ragged_lattices(group, L):
     """Smallest lattice, extents that leave workgroups partly empty and that no (z,t) region
     cut divides, Ny/2 that does not divide the workgroup size: link by link against the checker."""
@@ -195,7 +199,7 @@ def test_small_and_ragged_lattices(group, L):
     lat.close()
 
 
-@pytest.mark.parametrize("group,L,beta", [(3, (8, 8, 4, 6), 6.0), (2, (6, 8, 6, 4), 2.4)])
+@pytest.mark.parametrize("group,L,beta", [(3, (8, 8, 4, 6), 6.0), (2, (6, 8, 6, 4), 2.4), (3, (5, 4, 3, 4), 6.0), (2, (4, 4, 5, 7), 2.4)])
 def test_overrelaxation_matches_checker_and_keeps_the_action(group, L, beta):
     """Heat-bath + overrelaxation (BASELINE config 2 names both; the reference has only the
     heat-bath, so overrelaxation is parity unpinned): link by link against the checker's
@@ -216,7 +220,7 @@ def test_overrelaxation_matches_checker_and_keeps_the_action(group, L, beta):
     lat.close()
 
 
-@pytest.mark.parametrize("group,L,beta", [(3, (6, 4, 8, 6), 6.0), (2, (4, 8, 6, 6), 2.4)])
+@pytest.mark.parametrize("group,L,beta", [(3, (6, 4, 8, 6), 6.0), (2, (4, 8, 6, 6), 2.4), (3, (5, 4, 6, 7), 6.0)])
 def test_wilson_loop_matches_checker(group, L, beta):
     import qcdgpu_amd as q
     from qcdgpu_amd import biglattice as bl
@@ -232,6 +236,10 @@ def test_wilson_loop_matches_checker(group, L, beta):
         with pytest.raises(q.QcdError):
             c.wilson_loop(0, 1)
     lat.close()
+    if any(n & 1 for n in L):
+        with pytest.raises(q.QcdError, match="odd"):
+            bl.make_gpu_slabs(group, L, beta, [2, L[0] - 2], nhit=5, rand_series=23)   # odd extents: one uncut lattice only
+        return
     big = bl.make_gpu_slabs(group, L, beta, [2, L[0] - 2], nhit=5, rand_series=23)
     with pytest.raises(q.QcdError):
         big.engines[0].ctx.wilson_loop(1, 1)                               # not on a slab
@@ -289,7 +297,7 @@ def test_errors_are_status_codes_not_exits():
             c.upload(np.zeros((12, 100, 4)))              # rowsize < sites
 
 
-@pytest.mark.parametrize("group,L", [(3, (6, 4, 8, 4)), (2, (4, 8, 6, 6))])
+@pytest.mark.parametrize("group,L", [(3, (6, 4, 8, 4)), (2, (4, 8, 6, 6)), (3, (5, 4, 3, 6))])
 def test_plane_profiles_match_checker(group, L):
     """Plane-resolved plaquette and Polyakov-loop sums (the reference's lattice_action_diff_* and
     lattice_polyakov_diff_* kernels; device path only there, so no reference output to pin them):

@@ -108,13 +108,16 @@ def test_no_device_is_an_error_code_not_a_crash():
         q.Context(group=3, L=(4, 4, 4, 4), beta=6.0)
 
 
-def test_odd_extents_are_refused_before_any_device_work():
-    """Links and scalar field are stored by parity; an odd extent would make a site and its neighbour
-    across the periodic wrap the same parity.  Both engines say so instead of computing nonsense."""
+def test_odd_extents_where_they_are_refused():
+    """Ny must be even (the reference pairs sites 2h, 2h+1 in y).  Odd Nx, Nz, Nt: one uncut SU(N) lattice is served
+    (tests/test_gpu_parity.py), x-slabs and the scalar model's engine say that they are not instead of computing
+    nonsense -- before any device work."""
     import qcdgpu_amd as q
-    for L in ((5, 4, 4, 4), (4, 4, 3, 4), (4, 4, 4, 7), (4, 5, 4, 4)):
-        with pytest.raises(q.QcdError, match="odd|even"):
-            q.Context(group=3, L=L, beta=6.0)
+    with pytest.raises(q.QcdError, match="even"):
+        q.Context(group=3, L=(4, 5, 4, 4), beta=6.0)
+    for L in ((5, 4, 4, 4), (4, 4, 3, 4), (4, 4, 4, 7)):
+        with pytest.raises(q.QcdError, match="odd"):
+            q.Context(group=3, L=L, beta=6.0, x0=0, nx_local=2, halo=1)
         with pytest.raises(q.QcdError, match="odd|even"):
             q.OnContext(L=L)
 
