@@ -42,7 +42,8 @@ enum { QCD_START_HOT = 0, QCD_START_COLD = 1, QCD_START_GID = 2 };
 typedef struct {
     int      group;        /* lattice_group: 2 or 3 */
     int      nd;           /* lattice_nd: 4 */
-    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (all even: QCD_ERR_UNSUPPORTED otherwise) */
+    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt.  Ny even (coord_work.cpp:151-175); odd Nx, Nz, Nt for a
+                              context that owns the whole lattice (halo = 0) only */
     int      precision;    /* 2 = double, 1 = single, 3 = mixed (model::convert_precision_to_uint,
                               SU(N)/suncl/suncl.cpp:732-737); must be what qcd_precision() reports (3 counts as 1) */
     double   beta;         /* BETA */
@@ -55,6 +56,12 @@ typedef struct {
     int      nx_local;     /* number of x slices owned (SubLattice::Nx); even, or the whole lattice */
     int      halo;         /* 0: periodic in x inside the context; 1: two halo slices, filled by
                               qcd_halo_unpack (BigLattice geometry, suncl.cpp:2131-2148) */
+    double   phi, omega;   /* PHI, OMEGA: twisted boundary condition (-D TBC when one of them is not 0,
+                              suncl.cpp:3286).  Every READ of U_y at x = Nx-1 by an update or a measurement returns
+                              Omega U_y, Omega = diag(e^{i(phi+omega)/2}, e^{i(omega-phi)/2}, e^{-i omega}) for SU(3)
+                              (su3_matrix_memory.cl:57-98, su3cpu.cpp:165-197), diag(e^{i phi/2}, e^{-i phi/2}) for SU(2)
+                              (su2_matrix_memory.cl:63-88); an updated link is stored as it comes out of the heat-bath
+                              (suncl.cl:525-536), re-unitarisation and the link tables see the stored values.  halo = 0 only. */
 } qcd_params;
 
 typedef struct {
@@ -305,7 +312,8 @@ typedef struct qcd_on_ctx qcd_on_ctx;
 /* run_parameters of the O(N) model (O(N)/suncl/suncl.h:74-102; init keys SKGROUP, ON_Z, ON_LAMBDA,
  * ON_ZETA, ON_ETA, ON_B, O(N)/suncl/suncl.cpp:273-286) */
 typedef struct {
-    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt (all even: QCD_ERR_UNSUPPORTED otherwise) */
+    int      L[4];         /* lattice_full_size: Nx, Ny, Nz, Nt.  Ny even (coord_work.cpp:151-175); odd Nx, Nz, Nt for a
+                              context that owns the whole lattice (halo = 0) only */
     int      precision;    /* 0 = single, 1 = double (model_precision_single / _double) */
     int      nhit;         /* NHIT: proposals per site and pass */
     int      sk_group;     /* ON_SK_group: N of the O(N) group in the action */

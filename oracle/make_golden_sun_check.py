@@ -34,6 +34,10 @@ CASES = {
     # SU(2): Pauli matrices, index1 3 or 1, index2 2 (SU(N)/suncl/suncl.cpp:2094-2101)
     "su2_4x4x4x6": dict(group=2, L=(4, 4, 4, 6), beta=2.3, nhit=6, sweeps=3, field=1, idx=(3, 2), wilson=(2, 2)),
     "su2_6x4x4x4": dict(group=2, L=(6, 4, 4, 4), beta=1.5, nhit=4, sweeps=2, field=2, idx=(1, 2), wilson=(1, 3)),
+    # twisted boundary condition (PHI, OMEGA): the re-measurement multiplies U_y at x = N1 - 1 by Omega on every read
+    "4x4x6x4_H38_tw": dict(L=(4, 4, 6, 4), beta=5.8, nhit=8, sweeps=3, field=1, idx=(3, 8), wilson=(2, 2), phi=0.7, omega=-0.4),
+    "6x4x4x4_E38_tw": dict(L=(6, 4, 4, 4), beta=6.0, nhit=8, sweeps=2, field=2, idx=(3, 8), wilson=(3, 2), phi=0.0, omega=1.1),
+    "su2_4x6x4x4_tw": dict(group=2, L=(4, 6, 4, 4), beta=2.4, nhit=6, sweeps=3, field=1, idx=(3, 2), wilson=(2, 2), phi=0.9, omega=0.0),
 }
 
 
@@ -52,6 +56,8 @@ def main():
             table.tofile(f.name)
             args = [REF, str(group)] + [str(v) for v in c["L"]] + [str(rowsize), repr(c["beta"]), str(c["field"]), str(c["idx"][0]),
                                                       str(c["idx"][1]), str(c["wilson"][0]), str(c["wilson"][1]), f.name]
+            if "phi" in c:
+                args += [repr(c["phi"]), repr(c["omega"])]
             out = subprocess.run(args, check=True, capture_output=True, text=True).stdout
         exp = {}
         for line in out.splitlines():
@@ -60,7 +66,8 @@ def main():
         np.save(os.path.join(OUT, stem + ".npy"), table)
         doc = dict(source="oracle/_ref/qcdgpu_sun_check (reference SU(N)/suncl/su3cpu.cpp / su2cpu.cpp lattice_check_cpu, double precision)",
                    group=group, L=list(c["L"]), beta=c["beta"], field=c["field"], index1=c["idx"][0], index2=c["idx"][1],
-                   wilson_R=c["wilson"][0], wilson_T=c["wilson"][1], table=stem + ".npy", expected=exp)
+                   wilson_R=c["wilson"][0], wilson_T=c["wilson"][1], table=stem + ".npy", expected=exp,
+                   phi=c.get("phi", 0.0), omega=c.get("omega", 0.0))
         with open(os.path.join(OUT, stem + ".json"), "w") as fo:
             json.dump(doc, fo, indent=1)
         print(name, {k: exp[k] for k in ("Plq_spat", "Polyakov_loop", "Wilson_loop", "F_a_3_re")})

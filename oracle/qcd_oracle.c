@@ -592,6 +592,59 @@ void qo_overrelax_link3(qo_su3 *U, const qo_su3 *stap)
 /* ------------------------------------------------------------------------- */
 /* staples and passes: SU(N)/suncpp/Update/sun_update.h                         */
 
+/* ---- twisted boundary condition: the table holds Omega U_y on the slice x = Nx-1 while a pass or a measurement
+ * reads it; afterwards every link the pass did not update gets its stored value back */
+void qo_set_twist(qo_lattice *lat, double phi, double omega)
+{
+    lat->phi = phi;
+    lat->omega = omega;
+}
+static int twisted(const qo_lattice *lat) { return lat->phi != 0.0 || lat->omega != 0.0; }
+static void twist_begin(const qo_lattice *clat)
+{
+    qo_lattice *lat = (qo_lattice *)clat;
+    if (!twisted(lat) || lat->tw_depth++ > 0) return;
+    const int slice = lat->L[1] * lat->L[2] * lat->L[3], first = (lat->L[0] - 1) * slice, nd = lat->nd;
+    const size_t esz = (lat->group == 3) ? sizeof(qo_su3) : sizeof(qo_su2);
+    lat->tw_backup = malloc((size_t)slice * esz);
+    for (int k = 0; k < slice; k++) {
+        const int gid = first + k;
+        if (lat->group == 3) {
+            qo_su3 *m = &((qo_su3 *)lat->links)[gid * nd + 1];
+            ((qo_su3 *)lat->tw_backup)[k] = *m;
+            const double t1 = 0.5 * (lat->phi + lat->omega), t2 = 0.5 * (lat->omega - lat->phi);
+            const qo_cplx p1 = { cos(t1), sin(t1) }, p2 = { cos(t2), sin(t2) };
+            m->u1 = cmul(m->u1, p1); m->u2 = cmul(m->u2, p1); m->u3 = cmul(m->u3, p1);
+            m->v1 = cmul(m->v1, p2); m->v2 = cmul(m->v2, p2); m->v3 = cmul(m->v3, p2);
+            reconstruct3(m);
+        } else {
+            qo_su2 *m = &((qo_su2 *)lat->links)[gid * nd + 1];
+            ((qo_su2 *)lat->tw_backup)[k] = *m;
+            const qo_cplx p1 = { cos(0.5 * lat->phi), sin(0.5 * lat->phi) };
+            m->u1 = cmul(m->u1, p1); m->u2 = cmul(m->u2, p1);
+            m->v1.re = -m->u2.re; m->v1.im = m->u2.im;      /* second row from the first, algebra_su2.cpp:137-142 */
+            m->v2.re = m->u1.re;  m->v2.im = -m->u1.im;
+        }
+    }
+}
+/* updated_parity >= 0: the pass over direction y on that parity has replaced those links; they stay */
+static void twist_end(const qo_lattice *clat, int updated_parity)
+{
+    qo_lattice *lat = (qo_lattice *)clat;
+    if (!twisted(lat) || --lat->tw_depth > 0) return;
+    const int slice = lat->L[1] * lat->L[2] * lat->L[3], first = (lat->L[0] - 1) * slice, nd = lat->nd;
+    for (int k = 0; k < slice; k++) {
+        const int gid = first + k;
+        int c[4];
+        qo_gid_to_coords(lat->L, (unsigned)gid, c);
+        if (updated_parity >= 0 && ((c[0] + c[1] + c[2] + c[3]) & 1) == updated_parity) continue;
+        if (lat->group == 3) ((qo_su3 *)lat->links)[gid * nd + 1] = ((qo_su3 *)lat->tw_backup)[k];
+        else ((qo_su2 *)lat->links)[gid * nd + 1] = ((qo_su2 *)lat->tw_backup)[k];
+    }
+    free(lat->tw_backup);
+    lat->tw_backup = NULL;
+}
+
 void qo_staple3(const qo_lattice *lat, int gid, int dir, qo_su3 *out)
 {
     /* :43-77 */
@@ -657,6 +710,7 @@ void qo_update_pass(qo_lattice *lat, int parity, int dir)
     const int nd = lat->nd;
     const int gid_start = (lat->ints == 2);
     const double beta_eff = lat->beta / lat->group;
+    twist_begin(lat);
     for (int i = 0; i < lat->sites / 2; i++) {
         int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
         qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[i] : &lat->seq;
@@ -677,6 +731,7 @@ void qo_update_pass(qo_lattice *lat, int parity, int dir)
             tab[gid * nd + dir] = U;
         }
     }
+    twist_end(lat, dir == 1 ? parity : -1);
 }
 
 /* the same pass restricted to the sites with x in [x_begin, x_end): what one slab of a lattice
@@ -762,6 +817,7 @@ static void plaquette_sums_range(const qo_lattice *lat, int gid_begin, int gid_e
 {
     const int nd = lat->nd;
     double re = 0.0, im = 0.0;
+    twist_begin(lat);
     for (int gid = gid_begin; gid < gid_end; gid++) {
         for (int dir = 0; dir < nd - 2; dir++)
             for (int dir1 = dir + 1; dir1 < nd - 1; dir1++) {
@@ -799,6 +855,7 @@ static void plaquette_sums_range(const qo_lattice *lat, int gid_begin, int gid_e
             }
         }
     }
+    twist_end(lat, -1);
     *spat = re;
     *temp = im;
 }
@@ -843,6 +900,7 @@ static qo_su2 line2(const qo_lattice *lat, int gid, int dir, int len, int *end)
 double qo_wilson_loop(const qo_lattice *lat, int R, int T)
 {
     double sum = 0.0;
+    twist_begin(lat);
     for (int gid = 0; gid < lat->sites; gid++) {
         int pT, pR, dummy;
         if (lat->group == 3) {
@@ -871,6 +929,7 @@ double qo_wilson_loop(const qo_lattice *lat, int R, int T)
             }
         }
     }
+    twist_end(lat, -1);
     return sum / (3.0 * lat->sites);
 }
 
@@ -967,6 +1026,7 @@ static void polyakov_sums_range(const qo_lattice *lat, int x_begin, int x_end, d
 void qo_plaquette_profile_sums(const qo_lattice *lat, int axis, double *out)
 {
     for (int i = 0; i < 2 * lat->L[axis]; i++) out[i] = 0.0;
+    twist_begin(lat);
     for (int gid = 0; gid < lat->sites; gid++) {
         int c[4];
         double s, t;
@@ -975,6 +1035,7 @@ void qo_plaquette_profile_sums(const qo_lattice *lat, int axis, double *out)
         out[2 * c[axis]] += s;
         out[2 * c[axis] + 1] += t;
     }
+    twist_end(lat, -1);
 }
 
 void qo_polyakov_profile_sums(const qo_lattice *lat, int axis, double *out)
@@ -1053,6 +1114,7 @@ void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, dou
     const qo_su3 l1 = gell_mann(index1), l2 = gell_mann(index2);
     static const int planes[2][3][2] = { { {0, 1}, {0, 2}, {1, 2} }, { {0, 3}, {1, 3}, {2, 3} } };
     for (int i = 0; i < 12; i++) out[i] = 0.0;
+    twist_begin(lat);
     if (lat->group != 3) {
         /* SU(2): Pauli matrices, SU(N)/suncl/su2cpu.cpp:496-545, 716-870 */
         const qo_su2 *t2 = (const qo_su2 *)lat->links;
@@ -1078,6 +1140,7 @@ void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, dou
                     out[6 * a + 2 * k + 1] += -(t.u1.re + t.v2.re) / 2;
                 }
             }
+        twist_end(lat, -1);
         return;
     }
     for (int gid = 0; gid < lat->sites; gid++)
@@ -1094,6 +1157,7 @@ void qo_fmunu_sums(const qo_lattice *lat, int field, int index1, int index2, dou
             out[6 + 2 * k] += (t2.u1.im + t2.v2.im + t2.w3.im) / 2;
             out[6 + 2 * k + 1] += -(t2.u1.re + t2.v2.re + t2.w3.re) / 2;
         }
+    twist_end(lat, -1);
 }
 
 void qo_estimates(const double *data, int n, double *mean_out, double *var_out)

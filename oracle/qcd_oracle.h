@@ -56,6 +56,11 @@ typedef struct {
     qo_ranlux seq;        /* the one sequential stream */
     qo_ranlux *streams;   /* sites/2 streams in QO_RNG_PERSITE mode */
     unsigned long long rng_draws; /* numbers consumed (all modes but gid) */
+    /* twisted boundary condition (device path and CPU re-measurement of the reference only; its sequential CPU
+     * program has none): see qo_set_twist */
+    double phi, omega;
+    void *tw_backup;      /* the stored U_y links of the slice x = Nx-1 while the table holds their twisted form */
+    int tw_depth;
 } qo_lattice;
 
 /* glibc rand() restated (TYPE_3 additive feedback), so that seeds do not depend on the libc */
@@ -88,6 +93,14 @@ void   qo_matrix_gid2(qo_su2 *a, int gid, int dir, int sites);
 /* hot-start links from 12 / 4 uniform numbers (device path of the reference only; "parity unpinned") */
 void   qo_hot_link3(qo_su3 *m, const float r[12]);
 void   qo_hot_link2(qo_su2 *m, const float r[4]);
+
+/* Twisted boundary condition, PHI / OMEGA of the reference (-D TBC, SU(N)/suncl/suncl.cpp:3286).  Every read of U_y at
+ * x = Nx-1 by an update pass or a measurement returns Omega U_y: SU(3) Omega = diag(e^{i(phi+omega)/2}, e^{i(omega-phi)/2},
+ * e^{-i omega}) (SU(N)/suncl/su3_matrix_memory.cl:57-98, CPU re-measurement SU(N)/suncl/su3cpu.cpp:165-197), SU(2) Omega =
+ * diag(e^{i phi/2}, e^{-i phi/2}) (su2_matrix_memory.cl:63-88, su2cpu.cpp:164-183).  An updated link is stored as the heat-bath
+ * returns it, without taking the twist off (SU(N)/suncl/suncl.cl:525-536).  Measurements: pinned by the reference's CPU
+ * re-measurement; update pass: device only in the reference, "parity unpinned". */
+void qo_set_twist(qo_lattice *lat, double phi, double omega);
 
 /* lattice life cycle */
 qo_lattice *qo_create(int group, const int L[4], double beta, int nhit, int ints,

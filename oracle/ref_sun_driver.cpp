@@ -7,7 +7,10 @@
 // this file only fills in the public members those functions read -- no OpenCL device is touched
 // (model's and GPU's constructors only initialise members, SU(N)/suncl/suncl.cpp:142-214).
 //
-//   qcdgpu_sun_check group n1 n2 n3 n4 rowsize beta fmunu(0 none,1 H,2 E) index1 index2 wilsonR wilsonT table.bin
+//   qcdgpu_sun_check group n1 n2 n3 n4 rowsize beta fmunu(0 none,1 H,2 E) index1 index2 wilsonR wilsonT table.bin [PHI OMEGA]
+//
+// PHI, OMEGA: the twisted boundary condition, which the re-measurement applies to every U_y it reads at x = n1 - 1
+// (SU(N)/suncl/su3cpu.cpp:165-197, su2cpu.cpp:164-183).
 //
 // table.bin: 12 (SU(3)) or 4 (SU(2)) rows of rowsize double4 (SU(N)/suncl/su3_matrix_memory.cl:42-176,
 // su2_matrix_memory.cl:55-142).  Prints one
@@ -22,10 +25,11 @@
 
 int main(int argc, char** argv)
 {
-    if (argc != 14) {
-        fprintf(stderr, "usage: %s group n1 n2 n3 n4 rowsize beta fmunu index1 index2 wilsonR wilsonT table.bin\n", argv[0]);
+    if (argc != 14 && argc != 16) {
+        fprintf(stderr, "usage: %s group n1 n2 n3 n4 rowsize beta fmunu index1 index2 wilsonR wilsonT table.bin [PHI OMEGA]\n", argv[0]);
         return 2;
     }
+    const double phi = argc == 16 ? atof(argv[14]) : 0.0, omega = argc == 16 ? atof(argv[15]) : 0.0;
     const int group = atoi(argv[1]);
     argv++;
     model_CL::model* lat = new model_CL::model;
@@ -45,8 +49,8 @@ int main(int argc, char** argv)
     lat->get_wilson_loop = lat->wilson_R > 0;
     lat->get_plaquettes_avr = true;
     lat->precision = model_CL::model::model_precision_double;
-    lat->PHI = 0.0;
-    lat->OMEGA = 0.0;
+    lat->PHI = phi;
+    lat->OMEGA = omega;
     // derived members, as model::lattice_init / model_lattice_init set them (SU(N)/suncl/suncl.cpp:2212-2384)
     lat->lattice_domain_n1 = n1;
     lat->lattice_domain_n2n3 = n2 * n3;

@@ -527,6 +527,8 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     if (((p->L[0] | p->L[2] | p->L[3]) & 1) && p->halo)
         return fail(QCD_ERR_UNSUPPORTED, "odd lattice extents (%d x %d x %d x %d) are supported for one uncut lattice only, not for x-slabs", p->L[0],
                     p->L[1], p->L[2], p->L[3]);
+    if ((p->phi != 0.0 || p->omega != 0.0) && (p->halo || ((p->L[0] | p->L[2] | p->L[3]) & 1)))
+        return fail(QCD_ERR_UNSUPPORTED, "twisted boundary conditions (PHI, OMEGA) are supported for one uncut lattice with even extents only");
     if (p->nhit < 1) return fail(QCD_ERR_INVALID, "NHIT = %d < 1", p->nhit);
     if (p->lux_level < 0 || p->lux_level > 4) return fail(QCD_ERR_INVALID, "RANLUX level %d not in 0..4", p->lux_level);
     if (p->rand_series == 0) return fail(QCD_ERR_INVALID, "RANDSERIES = 0 (time seed) must be resolved by the host");
@@ -570,6 +572,15 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     g.gsites = (int)sites;
     g.gslice = g.ny * g.nz * g.nt;
     g.odd = (p->L[0] & 1) | ((p->L[2] & 1) << 2) | ((p->L[3] & 1) << 3);
+    g.tw[0] = g.tw[2] = 1.0;
+    g.tw[1] = g.tw[3] = 0.0;
+    if (p->phi != 0.0 || p->omega != 0.0) {
+        // SU(3): rows times e^{i (phi + omega) / 2} and e^{i (omega - phi) / 2} (su3_matrix_memory.cl:66-95); SU(2): e^{i phi / 2}
+        g.odd |= 16;
+        const double t1 = p->group == 3 ? 0.5 * (p->phi + p->omega) : 0.5 * p->phi, t2 = 0.5 * (p->omega - p->phi);
+        g.tw[0] = cos(t1); g.tw[1] = sin(t1);
+        g.tw[2] = cos(t2); g.tw[3] = sin(t2);
+    }
     // (z,t) regions for the 8 XCDs: the split with the smallest cut surface that divides both
     // extents; none -> one region (plain linear order)
     g.nzr = g.ntr = 1;
@@ -864,6 +875,8 @@ int qcd_overrelax(qcd_ctx* c, int parity, int dir)
     if (rc) return rc;
     if (parity != 0 && parity != 1) return fail(QCD_ERR_INVALID, "parity %d", parity);
     if (dir < 0 || dir > 3) return fail(QCD_ERR_INVALID, "direction %d", dir);
+    // the reference stores an updated link without taking the twist off again: a reflection stored that way is not microcanonical
+    if (c->g.odd & 16) return fail(QCD_ERR_UNSUPPORTED, "overrelaxation with twisted boundary conditions");
     Timed tm(c, 0);
     rc = (c->p.group == 3) ? launch_overrelax<3>(c, parity, dir) : launch_overrelax<2>(c, parity, dir);
     if (rc) return rc;

@@ -275,7 +275,9 @@ void model::lattice_init(void)
     if ((qcd_precision() == 2) != (precision == model_precision_double))
         throw model_error(qcd_precision() == 2 ? "this program is linked with the double-precision library: run qcdgpu_f32 for single or mixed precision"
                                                : "this program is linked with the single-precision library: run qcdgpu for double precision");
-    if (PHI != 0.0 || OMEGA != 0.0) throw model_error("twisted boundary conditions (PHI, OMEGA) are not implemented");
+    // twisted boundary conditions (-D TBC, SU(N)/suncl/suncl.cpp:3286): one uncut lattice, no overrelaxation sweeps
+    if ((PHI != 0.0 || OMEGA != 0.0) && (lattice_Nparts > 1 || NOVERRELAX > 0))
+        throw model_error("twisted boundary conditions (PHI, OMEGA) are implemented for one uncut lattice and heat-bath sweeps only");
     if ((get_Fmunu || get_F0mu) && lattice_group == 2) {
         // Fmunu_defaults, SU(N)/suncl/suncl.cpp:2094-2101: Pauli matrices, first index 3 or 1, second 2
         Fmunu_index1 = Fmunu_index1 == 1 ? 1 : 3;
@@ -308,6 +310,8 @@ void model::lattice_init(void)
         p.nd = lattice_nd;
         for (int i = 0; i < 4; i++) p.L[i] = lattice_full_size[i];
         p.precision = (int)precision_word();
+        p.phi = PHI;
+        p.omega = OMEGA;
         p.beta = BETA;
         p.nhit = NHIT;
         p.start_mode = (ints == model_start_hot) ? QCD_START_HOT : (ints == model_start_gid ? QCD_START_GID : QCD_START_COLD);

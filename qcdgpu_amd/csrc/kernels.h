@@ -998,6 +998,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h;
     g.tz = ap->g.tz; g.tt = ap->g.tt; g.tx = ap->g.tx;
     g.ux0 = ap->g.ux0; g.unx = ap->g.unx; g.odd = ap->g.odd;
+    if (ANY) { g.tw[0] = ap->g.tw[0]; g.tw[1] = ap->g.tw[1]; g.tw[2] = ap->g.tw[2]; g.tw[3] = ap->g.tw[3]; }
     const int parity = ap->parity;
     const int nhit = ap->nhit;
     const real beta_eff = (real)ap->beta_eff;
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
         mat<GROUP> A, Ul;
         if constexpr (ANY) {
             A = staple_any<GROUP, DIR>(U, g, x);
-            Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
+            Ul = load_site_link<GROUP>(U, g, DIR, x);   // twisted like every link that is read, stored as it comes out (suncl.cl:525-536)
             if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
         } else if constexpr (GROUP == 3) {
             // the stream's state is requested as soon as the staple's registers are free (requesting

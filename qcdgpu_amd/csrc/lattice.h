@@ -51,7 +51,10 @@ struct Geom {
     // bit d set: the extent in direction d (0 x, 2 z, 3 t; y is always even) is odd.  Across the periodic wrap of
     // such a direction a site's neighbour has the SAME parity; only the kernels that look a neighbour's parity
     // up per site (load_site_link) serve such a lattice, and a checkerboard pass runs in phases (update_phase)
-    int odd;
+    int odd;             // bit 4: twisted boundary condition (general kernels too, no phases of its own)
+    // twist (bit 4 of odd): U_y read at global x = Nx - 1 has its first row times (tw[0] + i tw[1]) and, SU(3), its second
+    // row times (tw[2] + i tw[3]); the last row follows from the rows before it as for every stored link
+    double tw[4];
 };
 
 struct Site {
@@ -186,11 +189,33 @@ __device__ __forceinline__ su2 load_link(const real2* __restrict__ U, const Geom
     reconstruct(m);
     return m;
 }
+// Omega U for the links the twisted boundary condition applies to (SU(N)/suncl/su3_matrix_memory.cl:57-98,
+// su2_matrix_memory.cl:63-88): rows times phases, then the dependent row again
+__device__ __forceinline__ void twist_link(su3& m, const Geom& g)
+{
+    const cplx p1 = mk((real)g.tw[0], (real)g.tw[1]), p2 = mk((real)g.tw[2], (real)g.tw[3]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        m.e[0][j] = cmul(m.e[0][j], p1);
+        m.e[1][j] = cmul(m.e[1][j], p2);
+    }
+    reconstruct(m);
+}
+__device__ __forceinline__ void twist_link(su2& m, const Geom& g)
+{
+    const cplx p1 = mk((real)g.tw[0], (real)g.tw[1]);
+    m.e[0][0] = cmul(m.e[0][0], p1);
+    m.e[0][1] = cmul(m.e[0][1], p1);
+    reconstruct(m);
+}
+// a link as updates and measurements see it
 template <int GROUP>
 __device__ __forceinline__ mat<GROUP> load_site_link(const real2* __restrict__ U, const Geom& g,
                                                      int dir, const Site& s)
 {
-    return load_link(U, g, dir, site_parity(g, s), half_index(g, s), (mat<GROUP>*)nullptr);
+    mat<GROUP> m = load_link(U, g, dir, site_parity(g, s), half_index(g, s), (mat<GROUP>*)nullptr);
+    if ((g.odd & 16) && dir == 1 && g.x0 + s.xs == g.gsites / g.gslice - 1) twist_link(m, g);
+    return m;
 }
 
 __device__ __forceinline__ void store_link(real2* __restrict__ U, const Geom& g, int dir, int par,

@@ -25,6 +25,8 @@ def _load():
     pi = C.POINTER(C.c_int)
     lib.qo_create.restype = P
     lib.qo_create.argtypes = [I, pi, D, I, I, I, I, U]
+    lib.qo_set_twist.argtypes = [P, D, D]
+    lib.qo_set_twist.restype = None
     lib.qo_destroy.argtypes = [P]
     lib.qo_init_links.argtypes = [P]
     lib.qo_sweep.argtypes = [P]
@@ -86,11 +88,13 @@ def _L(L):
 class Lattice:
     """One oracle lattice (links AoS [gid*nd+dir], full matrices)."""
 
-    def __init__(self, group, L, beta, nhit=10, ints=1, rng_mode=RNG_SEQ, lux=3, seed=54):
+    def __init__(self, group, L, beta, nhit=10, ints=1, rng_mode=RNG_SEQ, lux=3, seed=54, phi=0.0, omega=0.0):
         self.group, self.L = group, tuple(L)
         self.sites = int(np.prod(L))
         self.h = lib.qo_create(group, _L(L), beta, nhit, ints, rng_mode, lux, seed)
         lib.qo_init_links(self.h)
+        if phi or omega:
+            lib.qo_set_twist(self.h, phi, omega)   # twisted boundary condition (PHI, OMEGA)
 
     def close(self):
         if self.h:

@@ -34,7 +34,8 @@ def _ctx(**kw):
 def _check(a, b, rel=CHECK_REL):
     a, b = np.atleast_1d(np.asarray(a, float)), np.atleast_1d(np.asarray(b, float))
     big = (np.abs(a) > CHECK_FLOOR) & (np.abs(b) > CHECK_FLOOR)
-    assert np.all(np.abs(a[big] - b[big]) <= rel * np.abs(b[big])), (a, b)
+    # + 2e-7: averages of O(1) terms of both signs (Im P, Re P of a small lattice) carry float rounding of that size whatever they add up to
+    assert np.all(np.abs(a[big] - b[big]) <= rel * np.abs(b[big]) + 2e-7), (a, b)
     assert np.all(np.abs(a[~big] - b[~big]) <= 10 * CHECK_FLOOR), (a, b)
 
 

@@ -57,6 +57,32 @@ def test_cli_reproduces_reference_result_table(tmp_path, case):
     assert abs(mean - fx["summary"]["Mean Plq_total"]) < 1e-12 * abs(mean)
 
 
+def test_cli_twisted_boundary_condition(tmp_path):
+    """PHI / OMEGA in init.dat (the reference's keys, SU(N)/suncl/suncl.cpp:372-373): the host passes them on, the table is the
+    checker's twisted gid run, the header carries both angles, and a cut lattice or overrelaxation sweeps are refused."""
+    keys = dict(GROUP=3, ND=4, L1=4, L2=4, L3=6, L4=4, BETA=5.9, NHIT=6, INTS=2, PRNG="RANLUX3", RANDSERIES=54,
+                NAV=1, ITER=3, NITER=1, PHI=0.7, OMEGA=-0.4)
+    text, fields, rows, _ = _run(tmp_path, keys)
+    lat = ol.Lattice(3, (4, 4, 6, 4), 5.9, nhit=6, ints=2, rng_mode=ol.RNG_GID, phi=0.7, omega=-0.4)
+    want = [lat.plaquette()]
+    lat.sweep(1)
+    for _ in range(2):
+        lat.sweep(1)
+        want.append(lat.plaquette())
+    lat.close()
+    assert np.max(np.abs(rows[:, :3] - np.array(want)) / np.array(want)) < 1e-12
+    assert " PHI   (lambda_3)            : 7.0000000000000e-01" in text and " OMEGA (lambda_8)            : -4.0000000000000e-01" in text
+    for extra in ("\tN1 = {2, 2}\n\tDEVICE = {0, 0}\n", "\tNOVERRELAX = 1\n"):
+        d = tmp_path / ("x%d" % len(extra))
+        d.mkdir()
+        with open(d / "init.dat", "w") as f:
+            for k, v in keys.items():
+                f.write("\t%s = %s\n" % (k, v))
+            f.write(extra + "\tOUTPUTPATH = %s/\n" % d)
+        r = subprocess.run([QCDGPU, str(d / "init.dat")], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "twisted" in (r.stdout + r.stderr)
+
+
 def test_cli_biglattice_equals_single_lattice(tmp_path):
     """N1 = {..}: the lattice cut into x-slabs (two and three parts on one device, the way the
     reference exercises BigLattice on one GPU) gives the same run as the uncut lattice."""

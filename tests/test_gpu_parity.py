@@ -353,7 +353,7 @@ def test_observables_match_reference_cpu_remeasurement(fname):
         doc = json.load(f)
     table = np.load(os.path.join(ol.GOLDEN_DIR, doc["table"]), allow_pickle=False)
     e = doc["expected"]
-    with q.Context(group=3, L=doc["L"], beta=doc["beta"]) as c:
+    with q.Context(group=3, L=doc["L"], beta=doc["beta"], phi=doc.get("phi", 0.0), omega=doc.get("omega", 0.0)) as c:
         c.upload(table)
         plq, act, pol = c.plaquette(), c.action(), c.polyakov()
         w = c.wilson_loop(doc["wilson_R"], doc["wilson_T"])
@@ -386,7 +386,7 @@ def test_su2_observables_match_reference_cpu_remeasurement(fname):
         doc = json.load(f)
     table = np.load(os.path.join(ol.GOLDEN_DIR, doc["table"]), allow_pickle=False)
     e = doc["expected"]
-    with q.Context(group=2, L=doc["L"], beta=doc["beta"]) as c:
+    with q.Context(group=2, L=doc["L"], beta=doc["beta"], phi=doc.get("phi", 0.0), omega=doc.get("omega", 0.0)) as c:
         c.upload(table)
         plq, act, pol = c.plaquette(), c.action(), c.polyakov()
         w = c.wilson_loop(doc["wilson_R"], doc["wilson_T"])
@@ -531,3 +531,51 @@ def test_config3_su3_32_against_checker_fixture():
             assert c.rng_draws() == row["rng_draws"], row["sweep"]
             assert _rel(c.plaquette(), row["plaquette"]) < REL, row["sweep"]
             assert np.allclose(c.polyakov(), row["polyakov"], rtol=1e-9, atol=1e-13), row["sweep"]
+
+
+@pytest.mark.parametrize("group,L,phi,omega", [(3, (4, 4, 6, 4), 0.7, -0.4), (3, (6, 4, 4, 4), 0.0, 1.1), (2, (4, 6, 4, 4), 0.9, 0.0)])
+def test_twisted_boundary_condition_passes_match_checker(group, L, phi, omega):
+    """PHI / OMEGA: every read of U_y at x = Nx-1 is Omega U_y, an updated link is stored as the heat-bath returns it
+    (the reference's device path, SU(N)/suncl/su3_matrix_memory.cl:57-98, suncl.cl:525-536).  The reference has this on
+    its device path and in its CPU re-measurement only: measurements under the twist are pinned by the chk_*_tw
+    fixtures above, the update pass is **parity unpinned** and checked against the checker's restatement -- gid mode
+    link by link after every pass, then a RANLUX run with equal draw counts."""
+    import qcdgpu_amd as q
+    beta = 5.9 if group == 3 else 2.4
+    lat = ol.Lattice(group, L, beta, nhit=6, ints=2, rng_mode=ol.RNG_GID, phi=phi, omega=omega)
+    with _ctx(group=group, L=L, beta=beta, nhit=6, start_mode=q.START_GID, phi=phi, omega=omega) as c, \
+            _ctx(group=group, L=L, beta=beta, nhit=6, start_mode=q.START_GID) as plain:
+        c.init_lattice()
+        plain.init_lattice()
+        assert np.array_equal(c.download(), plain.download())                 # the stored start is the untwisted one
+        assert _rel(c.plaquette(), lat.plaquette()) < 1e-12
+        assert abs(c.plaquette()[2] - plain.plaquette()[2]) > 1e-4            # and the twist is seen by the measurement
+        for parity in (1, 0):
+            for d in range(4):
+                c.update(parity, d)
+                lat.update(parity, d)
+                assert np.max(np.abs(c.download() - lat.export_table())) < 1e-12, (parity, d)
+        assert _rel(c.plaquette(), lat.plaquette()) < 1e-12
+        assert abs(c.wilson_loop(2, 1) - lat.wilson_loop(2, 1)) < 1e-12
+        with pytest.raises(q.QcdError):
+            c.overrelax_sweep(1)                                               # not with a twist
+    lat.close()
+    lat = ol.Lattice(group, L, beta, nhit=6, ints=1, rng_mode=ol.RNG_PERSITE, seed=17, phi=phi, omega=omega)
+    with _ctx(group=group, L=L, beta=beta, nhit=6, rand_series=17, phi=phi, omega=omega) as c:
+        c.init_lattice()
+        for sweep in range(2):
+            c.sweep(1)
+            lat.sweep(1)
+            assert c.rng_draws() == ol.rng_draws(lat), sweep
+            assert _rel(c.plaquette(), lat.plaquette()) < REL, sweep
+        if group == 3:
+            for field in (0, 1):
+                assert np.allclose(c.fmunu(field, 3, 8, sums=True), lat.fmunu_sums(field, 3, 8), rtol=1e-9, atol=1e-11)
+        for axis in range(3):
+            assert np.allclose(c.plaquette_profile_sums(axis), lat.plaquette_profile_sums(axis), rtol=1e-11, atol=1e-11)
+    lat.close()
+    with pytest.raises(q.QcdError, match="twist"):
+        _ctx(group=group, L=L, beta=beta, x0=0, nx_local=2, halo=1, phi=phi, omega=omega)   # one uncut lattice only
+    with pytest.raises(q.QcdError, match="twist"):
+        _ctx(group=group, L=(L[0], L[1], L[2], 5), beta=beta, phi=phi, omega=omega)         # and even extents
+

@@ -267,7 +267,7 @@ def expected_fmunu(doc):
 def test_polyakov_wilson_fmunu_match_reference_cpu_code(fname):
     doc, table = load_check_case(fname)
     e = doc["expected"]
-    lat = ol.Lattice(3, doc["L"], doc["beta"], nhit=1, ints=1, rng_mode=ol.RNG_PERSITE)
+    lat = ol.Lattice(3, doc["L"], doc["beta"], nhit=1, ints=1, rng_mode=ol.RNG_PERSITE, phi=doc.get("phi", 0.0), omega=doc.get("omega", 0.0))
     lat.import_table(table)
     plq = lat.plaquette()
     act = lat.action()
@@ -291,7 +291,7 @@ def test_su2_polyakov_wilson_match_reference_cpu_code(fname):
     against the reference's SU(2) CPU re-measurement (SU(N)/suncl/su2cpu.cpp lattice_check_cpu)."""
     doc, table = load_check_case(fname)
     e = doc["expected"]
-    lat = ol.Lattice(2, doc["L"], doc["beta"], nhit=1, ints=1, rng_mode=ol.RNG_PERSITE)
+    lat = ol.Lattice(2, doc["L"], doc["beta"], nhit=1, ints=1, rng_mode=ol.RNG_PERSITE, phi=doc.get("phi", 0.0), omega=doc.get("omega", 0.0))
     lat.import_table(table)
     plq, act, pol = lat.plaquette(), lat.action(), lat.polyakov()
     assert np.allclose(plq[:2], [e["Plq_spat"], e["Plq_temp"]], rtol=1e-13)
