@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- link-updates/s of the SU(3) heat-bath sweep on MI355X (BASELINE.json metric).
+"""bench.py -- link-updates/s of the SU(3) heat-bath sweep on MI355X (the headline metric).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -316,7 +316,7 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     if world == 1 and not args.no_cpu:
-        # BASELINE configuration 5 beside the headline workload (not part of `value`): the O(N)
+        # the scalar-model configuration beside the headline workload (not part of `value`): the O(N)
         # scalar model, 64^4 in single precision, NHIT = 10, site updates per second from HIP events
         try:
             with q.OnContext((64, 64, 64, 64), precision=0, nhit=10, rand_series=7, device=local_rank) as oc:

@@ -417,7 +417,7 @@ def test_64x4_lattice_one_context_equals_two_slabs():
 
 
 def test_32x4_lattice_one_context_equals_eight_slabs():
-    """BASELINE configurations 3 and 4 at their stated size: SU(3) 32^4 in one context, and the same
+    """The benchmark's single-GPU and eight-GPU lattices at their stated size: SU(3) 32^4 in one context, and the same
     lattice cut the way an 8-GPU run cuts it, N1 = {4,4,4,4,4,4,4,4} (all parts on the one device
     of the box).  Nx = 4 per part: the split pass updates one slice next to either face first and
     leaves an interior of two.  Same plaquette sums (1e-13), Polyakov sums and counts of random

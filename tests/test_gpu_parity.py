@@ -201,7 +201,7 @@ def test_small_and_ragged_lattices(group, L):
 
 @pytest.mark.parametrize("group,L,beta", [(3, (8, 8, 4, 6), 6.0), (2, (6, 8, 6, 4), 2.4), (3, (5, 4, 3, 4), 6.0), (2, (4, 4, 5, 7), 2.4)])
 def test_overrelaxation_matches_checker_and_keeps_the_action(group, L, beta):
-    """Heat-bath + overrelaxation (BASELINE config 2 names both; the reference has only the
+    """Heat-bath + overrelaxation (the benchmark's 16^4 configuration names both; the reference has only the
     heat-bath, so overrelaxation is parity unpinned): link by link against the checker's
     restatement, and the plaquette average unchanged by microcanonical sweeps."""
     lat = ol.Lattice(group, L, beta, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE, seed=19)
@@ -246,7 +246,7 @@ def test_wilson_loop_matches_checker(group, L, beta):
 
 
 def test_config1_su3_16_plaquette_vs_cpu():
-    """BASELINE config 1: SU(3) 16^4 fp64 on one GPU, plaquette against the CPU path to 1e-12."""
+    """The benchmark's SU(3) 16^4 configuration: fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)
     lat = ol.Lattice(3, L, 6.0, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE)
     with _ctx(group=3, L=L, beta=6.0, nhit=10) as c:
@@ -495,7 +495,7 @@ def test_generator_state_round_trip_mid_sweep(beta, nhit):
 
 
 def test_config2_su3_16_heatbath_and_overrelaxation_vs_cpu():
-    """BASELINE configuration 2 at its stated size: SU(3) 16^4 fp64, heat-bath AND overrelaxation
+    """The benchmark's heat-bath + overrelaxation configuration at its stated size: SU(3) 16^4 fp64, heat-bath AND overrelaxation
     sweeps alternating, plaquette against the CPU path to 1e-12 after every sweep (the
     overrelaxation half has no counterpart in the reference: checked against the checker's
     restatement and by the action staying put)."""
@@ -518,7 +518,7 @@ def test_config2_su3_16_heatbath_and_overrelaxation_vs_cpu():
 
 
 def test_config3_su3_32_against_checker_fixture():
-    """BASELINE configuration 3 at its stated size: SU(3) 32^4, beta 6, cold start, two heat-bath
+    """The benchmark's headline lattice at its stated size: SU(3) 32^4, beta 6, cold start, two heat-bath
     sweeps against the CPU checker's per-thread-stream run of the same lattice (committed fixture,
     oracle/make_golden_persite32.py): plaquette to 1e-12, equal counts of random numbers drawn
     (the same accept/reject history at every one of 8.4 million link updates), Polyakov loop."""
