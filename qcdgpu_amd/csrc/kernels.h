@@ -1417,12 +1417,13 @@ __device__ __forceinline__ double retr_plaquette_su3_from(const rows2& a, const 
     }
     return re;
 }
+template <int AUX = 0>
 __device__ __forceinline__ double retr_plaquette_su3(const real2* __restrict__ U, const Geom& g, const unsigned ob,
                                                      const NbrOff& n, const int mu, const int nu,
                                                      const rows2& a, const rows2& d)
 {
-    const raw_link rb = issue_link(link_rsrc_both<3>(U, g, nu), g, (int)(ob + (unsigned)off_fwd(n, mu)));
-    const raw_link rc = issue_link(link_rsrc_both<3>(U, g, mu), g, (int)(ob + (unsigned)off_fwd(n, nu)));
+    const raw_link rb = issue_link<AUX>(link_rsrc_both<3>(U, g, nu), g, (int)(ob + (unsigned)off_fwd(n, mu)));
+    const raw_link rc = issue_link<AUX>(link_rsrc_both<3>(U, g, mu), g, (int)(ob + (unsigned)off_fwd(n, nu)));
     return retr_plaquette_su3_from(a, d, rb, rc);
 }
 
@@ -1530,6 +1531,15 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette(const real2* __restrict__ U
 // The kernel needs 257 registers in double precision, so a SIMD holds one wavefront and the 2048 of a 32^4 call
 // run in two rounds; capped at 256 (two wavefronts per SIMD, all resident) it takes the same 140 us with 7.4 M
 // L2 misses instead of 5.6 M: twice the columns in flight ask for twice the lines per step.
+// Cache policy of the marching kernel's requests (2 = non-temporal, see staple_aux): the neighbours inside the slice
+// were asked for by their owners one step earlier and are not needed after this step: with the hint on them a 32^4 call
+// has 4.5 M L2 misses instead of 5.6 M and takes 132.8 us instead of 134.3 (back-to-back calls); on the links of the
+// next slice or on U_x(x+nu) it costs time.
+#ifndef QCD_PLAQ_NT_NXT
+#define QCD_PLAQ_NT_NXT 0
+#define QCD_PLAQ_NT_IN 2
+#define QCD_PLAQ_NT_C 0
+#endif
 template <int BLOCK, int XSEG>
 __global__ __launch_bounds__(BLOCK) void k_plaquette_march(const real2* __restrict__ U, const Geom g,
                                                            double2* __restrict__ partial, double2* __restrict__ site_vals)
@@ -1564,18 +1574,18 @@ __global__ __launch_bounds__(BLOCK) void k_plaquette_march(const real2* __restri
             // the next site's y, z, t links (as this site's x neighbours), requested first
             raw_link nxt[3];
 #pragma unroll
-            for (int d = 1; d < 4; d++) nxt[d - 1] = issue_link(link_rsrc_both<3>(U, g, d), g, (int)(other_off + (unsigned)n.f0));
+            for (int d = 1; d < 4; d++) nxt[d - 1] = issue_link<QCD_PLAQ_NT_NXT>(link_rsrc_both<3>(U, g, d), g, (int)(other_off + (unsigned)n.f0));
             double sp = 0.0, tp = 0.0;
-            sp += retr_plaquette_su3(U, g, other_off, n, 1, 2, own[1], own[2]);
-            tp += retr_plaquette_su3(U, g, other_off, n, 1, 3, own[1], own[3]);
-            tp += retr_plaquette_su3(U, g, other_off, n, 2, 3, own[2], own[3]);
+            sp += retr_plaquette_su3<QCD_PLAQ_NT_IN>(U, g, other_off, n, 1, 2, own[1], own[2]);
+            tp += retr_plaquette_su3<QCD_PLAQ_NT_IN>(U, g, other_off, n, 1, 3, own[1], own[3]);
+            tp += retr_plaquette_su3<QCD_PLAQ_NT_IN>(U, g, other_off, n, 2, 3, own[2], own[3]);
             // planes with x: U_x(x) U_nu(x+xhat) (U_nu(x) U_x(x+nu))^+
             {
-                const raw_link c1 = issue_link(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f1));
+                const raw_link c1 = issue_link<QCD_PLAQ_NT_C>(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f1));
                 sp += retr_plaquette_su3_from(own[0], own[1], nxt[0], c1);
-                const raw_link c2 = issue_link(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f2));
+                const raw_link c2 = issue_link<QCD_PLAQ_NT_C>(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f2));
                 sp += retr_plaquette_su3_from(own[0], own[2], nxt[1], c2);
-                const raw_link c3 = issue_link(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f3));
+                const raw_link c3 = issue_link<QCD_PLAQ_NT_C>(link_rsrc_both<3>(U, g, 0), g, (int)(other_off + (unsigned)n.f3));
                 tp += retr_plaquette_su3_from(own[0], own[3], nxt[2], c3);
             }
             if (site_vals) {
