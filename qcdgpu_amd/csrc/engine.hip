@@ -103,6 +103,7 @@ struct qcd_ctx {
     struct { int slices; unsigned* flag; unsigned seq; } edge_sig = {0, nullptr, 0u};
     unsigned* edge_count = nullptr;
     int gh_mode;              // 0 never, 1 when the launch has at least 8 * gh_grid blocks, 2 whenever possible
+    unsigned gh_passes;       // whole-lattice passes run as the pair kernel so far (its parity picks the walking direction)
     hipStream_t own_stream, stream;
     real2* U;
     size_t U_elems;
@@ -206,6 +207,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
     a.phase = -1;
+    a.reverse = 0;
     a.edge_local = 0;
     a.edge_total = 0u;
     a.edge_seq = 0u;
@@ -249,6 +251,9 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
                 a.edge_count = c->edge_count;
                 a.edge_flag = c->edge_sig.flag;
             }
+            // every other whole-lattice pass walks the x-slices downwards (no edge signal: its edge blocks must come first)
+            static const int rev_env = getenv("QCDGPU_AMD_REVERSE") ? atoi(getenv("QCDGPU_AMD_REVERSE")) : 1;   // diagnostic override: 0 never
+            if (rev_env && edge_slices == 0 && xs_count == g.nx) a.reverse = (int)(c->gh_passes++ & 1u);
             const dim3 ggrid(c->gh_grid), gblock(512);
 #define QCD_LAUNCH_GH(D) hipLaunchKernelGGL((k_update_gh<D, NSKIP, GH_TEAMS>), ggrid, gblock, 0, stream, a)
             switch (dir) {

@@ -941,6 +941,8 @@ struct UpdArgs {
     unsigned long long* draws;
     int nblocks;   // blocks of BLOCK sites in the pass; workgroup b takes b, b + gridDim.x, ...
     int phase;     // lattices with an odd extent: only the sites of this phase are updated (update_phase); else -1
+    int reverse;   // pair kernel: walk the x-slices downwards (every other pass: the end of the pass before is what the
+                   // memory-side cache still holds)
     // Edge signal of a slab pass (edge_local = 0: none).  The first edge_local blocks of every
     // region are the slices next to the slab's two faces (the launch starts there); when the last
     // of them is stored and visible to the device, edge_seq is written to *edge_flag, on which
@@ -1170,13 +1172,15 @@ struct GhShared {
 
 // the team's it-th block of sites: workgroup b works for region b % regions, the teams of the
 // workgroups of a region take consecutive blocks of it; < 0: no more blocks
+// reverse: the blocks of a region taken from the last x-slice down to the first (see UpdArgs::reverse)
 template <int TEAMS>
-__device__ __forceinline__ int gh_block(const Geom& g, const int nblocks, const int team, const int it)
+__device__ __forceinline__ int gh_block(const Geom& g, const int nblocks, const int team, const int it, const int reverse = 0)
 {
     const int regions = g.nzr * g.ntr;
     const int wgs = (int)gridDim.x / regions;
-    const int local = (it * wgs + (int)blockIdx.x / regions) * TEAMS + team;
+    int local = (it * wgs + (int)blockIdx.x / regions) * TEAMS + team;
     if ((int)blockIdx.x >= wgs * regions || local >= nblocks / regions) return -1;
+    if (reverse) local = nblocks / regions - 1 - local;
     return local * regions + (int)blockIdx.x % regions;
 }
 
@@ -1189,14 +1193,14 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
 {
     QCD_GH_SPIN_DECL;
     const int parity = a.parity;
-    int wb = gh_block<TEAMS>(g, a.nblocks, team, 0);
+    int wb = gh_block<TEAMS>(g, a.nblocks, team, 0, a.reverse);
     if (wb < 0) return;
     SiteRef cur = site_ref<64>(g, wb, lane, parity);
     raw_pair ab = issue_ab<DIR, T0>(a.U, g, cur.hb, cur.nbr, parity);
     raw_link cl = issue_c<DIR, T0>(a.U, g, cur.hb, cur.nbr, parity);
 #pragma unroll 1
     for (int it = 0;; it++) {
-        const int wbn = gh_block<TEAMS>(g, a.nblocks, team, it + 1);
+        const int wbn = gh_block<TEAMS>(g, a.nblocks, team, it + 1, a.reverse);
         const bool has_next = wbn >= 0;
         SiteRef nxt = cur;
         if (has_next) nxt = site_ref<64>(g, wbn, lane, parity);
@@ -1285,7 +1289,7 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
         __builtin_amdgcn_s_setprio(QCD_PRIO_ALU);
 #pragma unroll 1
         for (int it = j;; it += PER) {
-            const int wb = gh_block<TEAMS>(g, a.nblocks, team, it);
+            const int wb = gh_block<TEAMS>(g, a.nblocks, team, it, a.reverse);
             if (wb < 0) break;
             const SiteRef cur = site_ref<64>(g, wb, lane, parity);
             const __amdgpu_buffer_rsrc_t r_own = link_rsrc<3>(a.U, g, DIR, parity);
