@@ -345,7 +345,7 @@ def main():
         try:
             with q.Context(group=3, L=L, beta=args.beta, nhit=10, device=local_rank, precision=1) as c32:
                 c32.init_lattice()
-                c32.sweep(args.warmup)
+                c32.sweep(max(args.warmup, 20))   # thermalised enough for steady accept rates (the headline leg has its brackets for that)
                 f_ms, f_launches = c32.timed_sweeps(args.steps)
                 f_pass_s = f_ms * 1e-3 / f_launches
                 f_bytes = 432.0 * (n ** 4) / 2      # 8 links read + 1 written, 48 B each, per updated link
