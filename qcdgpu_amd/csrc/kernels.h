@@ -1397,6 +1397,12 @@ __device__ __forceinline__ cplx cross_c(cplx a1, cplx a2, cplx b1, cplx b2)   //
 // the arithmetic: a, d two rows of U_mu(x), U_nu(x); rb = U_nu(x+mu), rc = U_mu(x+nu) as loaded
 __device__ __forceinline__ double retr_plaquette_su3_from(const rows2& a, const rows2& d, const raw_link& rb, const raw_link& rc)
 {
+#ifdef QCD_PLAQ_ABL   // diagnostic build: loads kept, arithmetic of a plane reduced to a few additions
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) acc += (double)rb.c[c].x + (double)rc.c[c].y;
+    return acc + (double)a.e[0][0].re + (double)d.e[1][1].im;
+#endif
     const su3 b = as_su3(rb);
     const su3 c = as_su3(rc);
     cplx p[2][3], q[2][3];
