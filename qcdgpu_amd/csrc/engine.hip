@@ -927,6 +927,15 @@ int qcd_reunitarize(qcd_ctx* c)
 }
 
 // the plaquette kernel with its per-workgroup partial sums going to `partial`; *nparts = how many
+// Slices per thread for the kernels that march along x: as long as the marching threads still fill the device
+static int march_segment(const Geom& g)
+{
+    const long fill = 40000;
+    if ((long)g.gslice * cdiv(g.nx, 8) >= fill) return 8;
+    if ((long)g.gslice * cdiv(g.nx, 4) >= fill) return 4;
+    return 1;
+}
+
 static int launch_plaquette_into(qcd_ctx* c, double2* partial, double2* site_vals, int* nparts)
 {
     const dim3 block(MEAS_BLOCK);
@@ -934,7 +943,8 @@ static int launch_plaquette_into(qcd_ctx* c, double2* partial, double2* site_val
         // x segments per thread: long enough that the links carried along x pay, short enough for the grid to fill the device
         static const int seg_env = getenv("QCDGPU_AMD_PLAQ_XSEG") ? atoi(getenv("QCDGPU_AMD_PLAQ_XSEG")) : 0;   // diagnostic override (1: one site per thread)
         const Geom& g = c->g;
-        const int xseg = g.odd ? 1 : (seg_env ? seg_env : ((long)g.gslice * cdiv(g.nx, 8) >= 256L * MEAS_BLOCK ? 8 : 4));
+        // (a call at 16^4: 14 us with one site per thread, 28 us with four; 24^4: 65 / 69 / 62 us with 1 / 4 / 8; 32^4: 156 / 145 / 141 us)
+        const int xseg = g.odd ? 1 : (seg_env ? seg_env : march_segment(g));
         if (xseg != 8 && xseg != 4) {
             hipLaunchKernelGGL((k_plaquette<3, MEAS_BLOCK>), dim3(c->npartial), block, 0, c->stream, c->U, c->g, partial, site_vals);
             *nparts = c->npartial;
@@ -1050,14 +1060,26 @@ int qcd_measure_fmunu_sums(qcd_ctx* c, int field, int index1, int index2, double
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     if (6L * c->npartial > c->partial_len) return fail(QCD_ERR_UNSUPPORTED, "reduction buffer too small");
     Timed tm(c, 1);
-    if (c->p.group == 3)
+    int nparts = c->npartial;
+    static const int march_env = getenv("QCDGPU_AMD_FMUNU_MARCH") ? atoi(getenv("QCDGPU_AMD_FMUNU_MARCH")) : 1;   // diagnostic override: 0 = one site per thread
+    const int xseg = (c->p.group == 3 && !c->g.odd && march_env) ? march_segment(c->g) : 1;
+    if (xseg > 1) {
+        const Geom& g = c->g;
+        nparts = cdiv((long)g.gslice * cdiv(g.nx, xseg), MEAS_BLOCK);
+        if (nparts > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
+        const dim3 grid(nparts), block(MEAS_BLOCK);
+        if (xseg == 8 && field) hipLaunchKernelGGL((k_fmunu_march<MEAS_BLOCK, 8, 1>), grid, block, 0, c->stream, c->U, c->g, index1, index2, c->partial, nparts);
+        else if (xseg == 8) hipLaunchKernelGGL((k_fmunu_march<MEAS_BLOCK, 8, 0>), grid, block, 0, c->stream, c->U, c->g, index1, index2, c->partial, nparts);
+        else if (field) hipLaunchKernelGGL((k_fmunu_march<MEAS_BLOCK, 4, 1>), grid, block, 0, c->stream, c->U, c->g, index1, index2, c->partial, nparts);
+        else hipLaunchKernelGGL((k_fmunu_march<MEAS_BLOCK, 4, 0>), grid, block, 0, c->stream, c->U, c->g, index1, index2, c->partial, nparts);
+    } else if (c->p.group == 3)
         hipLaunchKernelGGL((k_fmunu<3, MEAS_BLOCK>), dim3(c->npartial), dim3(MEAS_BLOCK), 0, c->stream, c->U, c->g, field, index1,
                            index2, c->partial, c->npartial);
     else
         hipLaunchKernelGGL((k_fmunu<2, MEAS_BLOCK>), dim3(c->npartial), dim3(MEAS_BLOCK), 0, c->stream, c->U, c->g, field, index1,
                            index2, c->partial, c->npartial);
     HIP_TRY(hipGetLastError());
-    rc = reduce_partials(c, c->npartial, 6, sums);
+    rc = reduce_partials(c, nparts, 6, sums);
     if (rc) return rc;
     return tm.finish();
 }

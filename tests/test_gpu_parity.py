@@ -245,6 +245,35 @@ def test_wilson_loop_matches_checker(group, L, beta):
         big.engines[0].ctx.wilson_loop(1, 1)                               # not on a slab
 
 
+@pytest.mark.parametrize("L,parts", [((16, 32, 32, 20), [8, 8]), ((20, 20, 20, 20), [16, 4])])
+def test_fmunu_marching_kernel_matches_checker(L, parts):
+    """F_mu_nu sums on lattices large enough for the kernel that marches along x (eight slices per thread on the first lattice,
+    four on the second; the reference's fixtures are all on small lattices, which take the one-site-per-thread kernel):
+    both fields against the checker on the same configuration after one sweep, and the same lattice cut into two
+    slabs, whose sums add up to the uncut lattice's."""
+    from qcdgpu_amd import biglattice as bl
+    lat = ol.Lattice(3, L, 5.7, nhit=3, ints=1, rng_mode=ol.RNG_PERSITE, seed=17)
+    lat.sweep(1)
+    want = {(f, a, b): lat.fmunu_sums(f, a, b) for f, a, b in ((0, 3, 8), (1, 3, 8), (0, 1, 6), (1, 2, 5), (1, 4, 7))}
+    plq = lat.plaquette()
+    lat.close()
+    with _ctx(group=3, L=L, beta=5.7, nhit=3, rand_series=17) as c:
+        c.init_lattice()
+        c.sweep(1)
+        assert _rel(c.plaquette(), plq) < REL
+        for key, w in want.items():
+            assert np.allclose(c.fmunu(*key, sums=True), w, rtol=1e-9, atol=1e-10), key
+    big = bl.make_gpu_slabs(3, L, 5.7, parts, nhit=3, rand_series=17)
+    try:
+        big.sweep(1)
+        for key, w in want.items():
+            got = np.sum([e.ctx.fmunu(*key, sums=True) for e in big.engines], axis=0)
+            assert np.allclose(got, w, rtol=1e-9, atol=1e-10), key
+    finally:
+        for e in big.engines:
+            e.ctx.close()
+
+
 def test_config1_su3_16_plaquette_vs_cpu():
     """The benchmark's SU(3) 16^4 configuration: fp64 on one GPU, plaquette against the CPU path to 1e-12."""
     L = (16, 16, 16, 16)
