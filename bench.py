@@ -123,7 +123,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=20)   # the first sweeps from the cold start run faster than thermalised ones
     ap.add_argument("--L", type=int, default=32, help="lattice extent per GPU (Nx per GPU, Ny, Nz, Nt)")
     ap.add_argument("--beta", type=float, default=6.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
