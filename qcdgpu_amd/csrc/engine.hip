@@ -1039,7 +1039,9 @@ int qcd_measure_wilson(qcd_ctx* c, int R, int T, double* out)
     if (nb > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
     Timed tm(c, 1);
     const dim3 grid(nb), block(MEAS_BLOCK);
-    if (c->p.group == 3) hipLaunchKernelGGL((k_wilson<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, R, T, c->partial);
+    static const int rows_env = getenv("QCDGPU_AMD_WILSON_ROWS") ? atoi(getenv("QCDGPU_AMD_WILSON_ROWS")) : 1;   // diagnostic override: 0 = full 3 x 3 products
+    if (c->p.group == 3 && !c->g.odd && rows_env) hipLaunchKernelGGL((k_wilson_rows<MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, R, T, c->partial);
+    else if (c->p.group == 3) hipLaunchKernelGGL((k_wilson<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, R, T, c->partial);
     else hipLaunchKernelGGL((k_wilson<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, R, T, c->partial);
     if ((rc = tm.finish())) return rc;
     double s[2];

@@ -1688,6 +1688,84 @@ __global__ __launch_bounds__(BLOCK) void k_wilson(const real2* __restrict__ U, c
     block_reduce_store<BLOCK>(sum, 0.0, partial);
 }
 
+// SU(3) on an uncut lattice with even extents: the same loop with every product kept as its first two rows (a line
+// and the two halves of the loop are SU(3) matrices, so a third row is the cross product of the other two and is only
+// formed where a matrix stands on the right of a product), buffer addressing, and the loop closed as
+// ReTr[(Tline(p) Rline_i(p + T t)) (Rline_i(p) Tline(p + R i))^+] with the rule of retr_plaquette_su3_from.
+__device__ __forceinline__ raw_link issue_site_link(const real2* __restrict__ U, const Geom& g, const int dir, const Site& s)
+{
+    const unsigned pbytes = (unsigned)ncomp<3>::value * (unsigned)g.vh_alloc * (unsigned)CB;
+    const unsigned off = (site_parity(g, s) ? pbytes : 0u) + (unsigned)half_index(g, s) * (unsigned)CB;
+    return issue_link(link_rsrc_both<3>(U, g, dir), g, (int)off);
+}
+__device__ __forceinline__ rows2 mul_rows(const rows2& a, const su3& b)
+{
+    rows2 p;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) p.e[i][j] = dot3(a.e[i][0], a.e[i][1], a.e[i][2], b.e[0][j], b.e[1][j], b.e[2][j]);
+    return p;
+}
+__device__ __forceinline__ su3 completed(const rows2& a)
+{
+    su3 m;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) m.e[i][j] = a.e[i][j];
+    reconstruct(m);
+    return m;
+}
+__device__ __forceinline__ rows2 link_line_rows(const real2* __restrict__ U, const Geom& g, Site& q, const int dir, const int len)
+{
+    rows2 m = as_rows2(issue_site_link(U, g, dir, q));
+    for (int k = 1; k < len; k++) {
+        q = fwd(g, q, dir);
+        m = mul_rows(m, as_su3(issue_site_link(U, g, dir, q)));
+    }
+    q = fwd(g, q, dir);   // the site behind the line's end
+    return m;
+}
+// Re Tr(P Q^+) of two SU(3) matrices given by their first two rows
+__device__ __forceinline__ double retr_rows(const rows2& p, const rows2& q)
+{
+    double re = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) re += (double)(p.e[i][j].re * q.e[i][j].re + p.e[i][j].im * q.e[i][j].im);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        const cplx cp = cross_c(p.e[0][j1], p.e[0][j2], p.e[1][j1], p.e[1][j2]);
+        const cplx cq = cross_c(q.e[0][j1], q.e[0][j2], q.e[1][j1], q.e[1][j2]);
+        re += (double)(cp.re * cq.re + cp.im * cq.im);
+    }
+    return re;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_wilson_rows(const real2* __restrict__ U, const Geom g, const int R, const int T,
+                                                       double2* __restrict__ partial)
+{
+    double sum = 0.0;
+    Site p;
+    if (measurement_site<BLOCK>(g, p)) {
+        Site pT = p;
+        const rows2 m1 = link_line_rows(U, g, pT, 3, T);
+#pragma unroll 1
+        for (int i = 0; i < 3; i++) {
+            Site pR = p, q2 = pT;
+            const rows2 m4 = link_line_rows(U, g, pR, i, R);
+            const rows2 m2 = link_line_rows(U, g, q2, i, R);
+            const rows2 m3 = link_line_rows(U, g, pR, 3, T);
+            sum += retr_rows(mul_rows(m1, completed(m2)), mul_rows(m4, completed(m3)));
+        }
+    }
+    block_reduce_store<BLOCK>(sum, 0.0, partial);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Polyakov loop (SU(N)/suncl/su3cpu.cpp:1383-1433; kernel lattice_polyakov,
 // SU(N)/suncl/polyakov.cl:53-141): P = Tr prod_{t=0}^{Nt-1} U_T(x,t), left to right from t = 0.
