@@ -1788,10 +1788,18 @@ __global__ __launch_bounds__(BLOCK) void k_polyakov(const real2* __restrict__ U,
         x.y = r - x.z * g.ny;
         x.t = 0;
         mat<GROUP> m = load_site_link<GROUP>(U, g, 3, x);
-        for (int tt = 1; tt < g.nt; tt++) {
-            x.t = tt;
-            const mat<GROUP> l = load_site_link<GROUP>(U, g, 3, x);
-            m = mul(m, l);
+        // four links requested before the first of them is multiplied in: one thread per line is a chain of Nt dependent
+        // products, and with one request in flight per thread the kernel waits a memory latency per link
+        for (int t0 = 1; t0 < g.nt; t0 += 4) {
+            mat<GROUP> l[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x.t = (t0 + k < g.nt) ? t0 + k : g.nt - 1;
+                l[k] = load_site_link<GROUP>(U, g, 3, x);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (t0 + k < g.nt) m = mul(m, l[k]);
         }
         const cplx tr = trace(m);
         re = tr.re;
