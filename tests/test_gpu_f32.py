@@ -212,6 +212,14 @@ def test_su3_32_pair_kernel_path():
         t = c.download()
         re_u, im_u = t[0][:, :3], t[4][:, :3]
         assert np.max(np.abs((re_u ** 2 + im_u ** 2).sum(axis=1) - 1.0)) < 1e-6
+        # at this size the plaquette and F_mu_nu kernels march along x, eight slices per thread: the same configuration
+        # measured by the double library
+        with _ctx(group=3, L=(32, 32, 32, 32), beta=6.0) as d:
+            d.upload(t.astype(np.float64))
+            _check(c.plaquette(), d.plaquette())
+            _check(c.wilson_loop(2, 3), d.wilson_loop(2, 3))
+            for field in (0, 1):
+                _check(c.fmunu(field, 3, 8), d.fmunu(field, 3, 8), rel=2e-4)
 
 
 def test_hot_start_and_state_round_trip():
