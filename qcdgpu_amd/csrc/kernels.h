@@ -129,14 +129,26 @@ struct RlxFast {
     // fetch: request the generator state in front of the stream's next batch
     __device__ __forceinline__ void fetch(RlxRegs& r) const
     {
-#ifndef QCD_ABL_RNG
+#if defined(QCD_ABL_RNG_MEM)   // diagnostic build: the generator runs, its state comes from nowhere and goes nowhere
+#pragma unroll
+        for (int k = 0; k < 24; k++) r.s[k] = (unsigned)(k * 2654435761u + (unsigned)(size_t)buf) & 0xFFFFFFu;
+        r.c = 0u;
+#elif !defined(QCD_ABL_RNG)
         h.load_state(r, cur);
 #endif
     }
     // generate: two delivered batches into LDS, the state between them made persistent
     __device__ __forceinline__ void generate(RlxRegs& r)
     {
-#ifndef QCD_ABL_RNG  // diagnostic build: no generator work, constant numbers
+#if defined(QCD_ABL_RNG_ALU)   // diagnostic build: the state travels, the generator does not run
+        h.store_state(r, cur ^ 1);
+#pragma unroll
+        for (int k = 0; k < 48; k++) buf[k * BLOCK] = 0.37f + 0.001f * (float)(k % 24);
+#elif defined(QCD_ABL_RNG_MEM)
+        rlx_batch(r, buf, BLOCK);
+        skip(r);
+        rlx_batch(r, buf + 24 * BLOCK, BLOCK);
+#elif !defined(QCD_ABL_RNG)  // diagnostic build: no generator work, constant numbers
         rlx_batch(r, buf, BLOCK);
         skip(r);
         h.store_state(r, cur ^ 1);   // in front of the second batch: the usual next state
@@ -284,7 +296,7 @@ struct RlxFast {
     // number of values used; leaves the stream's state in front of its next batch in slot cur ^ 1
     __device__ __forceinline__ int close()
     {
-#ifndef QCD_ABL_RNG
+#if !defined(QCD_ABL_RNG) && !defined(QCD_ABL_RNG_MEM) && !defined(QCD_ABL_RNG_ALU)
         if (pos > 24 * RLX_WINDOW) {
             slow_store();   // the slow form keeps the state in front of the next batch
         } else if (pos > 24) {
