@@ -253,7 +253,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
             }
             // every other whole-lattice pass walks the x-slices downwards (no edge signal: its edge blocks must come first)
             static const int rev_env = getenv("QCDGPU_AMD_REVERSE") ? atoi(getenv("QCDGPU_AMD_REVERSE")) : 1;   // diagnostic override: 0 never
-            if (rev_env && edge_slices == 0 && xs_count == g.nx) a.reverse = (int)(c->gh_passes++ & 1u);
+            if (rev_env && edge_slices == 0 && xs_count == g.nx) a.reverse = (int)((c->gh_passes++ + (rev_env == 2 ? 1u : 0u)) & 1u);   // 2: the other passes
             const dim3 ggrid(c->gh_grid), gblock(512);
 #define QCD_LAUNCH_GH(D) hipLaunchKernelGGL((k_update_gh<D, NSKIP, GH_TEAMS>), ggrid, gblock, 0, stream, a)
             switch (dir) {
