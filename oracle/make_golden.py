@@ -8,7 +8,7 @@ init.dat configurations, parses the "% 16.13e" data table it writes
 tests/golden/.  The fixtures are data only; the reference binary and its sources never
 enter the repository.
 
-usage: python3 oracle/make_golden.py            (needs oracle/_ref/qcdgpu_cpu)
+usage: python3 oracle/make_golden.py [case ...]   (needs oracle/_ref/qcdgpu_cpu; no names: every case)
 """
 import json
 import os
@@ -57,6 +57,11 @@ CASES = {
                             PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=4, NITER=1),
     "su3_4x4x4x7_cold_rl3": dict(GROUP=3, ND=4, L1=4, L2=4, L3=4, L4=7, BETA=6.0, NHIT=10, INTS=1,
                                  PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=3, NITER=1),
+    # the benchmark's lattice: one deterministic sweep of the reference at full size
+    "su3_32x32x32x32_gid": dict(GROUP=3, ND=4, LS=32, LT=32, BETA=6.0, NHIT=10, INTS=2,
+                                PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=2, NITER=1),
+    "su3_32x32x32x32_cold_rl3": dict(GROUP=3, ND=4, LS=32, LT=32, BETA=6.0, NHIT=10, INTS=1,
+                                     PRNG="RANLUX3", RANDSERIES=54, NAV=0, ITER=2, NITER=1),
     "su3_8x8x8x8_cold_rl4_lowbeta": dict(GROUP=3, ND=4, LS=8, LT=8, BETA=1.5, NHIT=2, INTS=1,
                                          PRNG="RANLUX4", RANDSERIES=4321, NAV=0, ITER=3,
                                          NITER=1),
@@ -105,6 +110,8 @@ def main():
         sys.exit("build the reference first: make -C oracle ref")
     os.makedirs(OUT, exist_ok=True)
     for name, keys in CASES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:   # case names on the command line: only those
+            continue
         res = run_case(name, keys)
         with open(os.path.join(OUT, "ref_%s.json" % name), "w") as f:
             json.dump(res, f, indent=1)
