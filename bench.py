@@ -142,6 +142,19 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    # a run that has not finished after this many seconds (a halo exchange that never completes, say) ends itself
+    # with a message instead of holding its GPUs until somebody else's limit strikes
+    import threading
+
+    def _give_up():
+        print("[bench] rank %d: no result after %s s, giving up" % (rank, os.environ.get("QCDGPU_BENCH_WATCHDOG", "600")),
+              file=sys.stderr, flush=True)
+        os._exit(3)
+
+    watchdog = threading.Timer(float(os.environ.get("QCDGPU_BENCH_WATCHDOG", "600")), _give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
     import torch
     import qcdgpu_amd as q   # raises if the HIP library is missing: no fallback
     from qcdgpu_amd import biglattice as bl
