@@ -1233,6 +1233,25 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
         }
         QCD_GH_TERM(0) QCD_GH_TERM(1) QCD_GH_TERM(2) QCD_GH_TERM(3) QCD_GH_TERM(4) QCD_GH_TERM(5)
 #undef QCD_GH_TERM
+#ifdef QCD_ABL_FUSE_LOADS   // diagnostic build: the x and z passes also request what the y and t staples of their sites need (values unused)
+        if constexpr (DIR == 0 || DIR == 2) {
+            constexpr int D2 = DIR + 1;
+            real acc = 0;
+#define QCD_GH_EXTRA(T)                                                                                  \
+            {                                                                                            \
+                raw_pair e = issue_ab<D2, T>(a.U, g, cur.hb, cur.nbr, parity);                           \
+                raw_link f = issue_c<D2, T>(a.U, g, cur.hb, cur.nbr, parity);                            \
+                pin(e);                                                                                  \
+                pin(f);                                                                                  \
+                _Pragma("unroll") for (int c = 0; c < 6; c++)                                            \
+                    acc += e.a.c[c].x + e.a.c[c].y + e.b.c[c].x + e.b.c[c].y + f.c[c].x + f.c[c].y;      \
+                asm volatile("" : "+v"(acc));                                                            \
+            }
+            QCD_GH_EXTRA(0) QCD_GH_EXTRA(1) QCD_GH_EXTRA(2) QCD_GH_EXTRA(3) QCD_GH_EXTRA(4) QCD_GH_EXTRA(5)
+#undef QCD_GH_EXTRA
+            stap.e[0][0].re += acc * (real)0;
+        }
+#endif
         const int s = it % GH_SLOTS;
         if (it >= GH_SLOTS) {
             // the slot is free once the heat-bath side has read block it - GH_SLOTS out of it
