@@ -1096,11 +1096,24 @@ int qcd_measure_fmunu(qcd_ctx* c, int field, int index1, int index2, double out[
 }
 
 // the loop of every owned space site into c->loops (and the four global sums into c->partial)
-static int launch_polyakov(qcd_ctx* c, int nb)
+// *nb: the number of partial sums per output it left
+static int launch_polyakov(qcd_ctx* c, int* nb)
 {
-    const dim3 grid(nb), block(MEAS_BLOCK);
-    if (c->p.group == 3) hipLaunchKernelGGL((k_polyakov<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb, c->loops);
-    else hipLaunchKernelGGL((k_polyakov<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nb, c->loops);
+    const int n3 = c->g.nx * c->g.ny * c->g.nz;
+    static const int split_env = getenv("QCDGPU_AMD_POLYAKOV_SPLIT") ? atoi(getenv("QCDGPU_AMD_POLYAKOV_SPLIT")) : 1;   // diagnostic override: 0 = one thread per line
+    const int nbs = cdiv(n3, MEAS_BLOCK / 4);
+    if (split_env && c->g.nt >= 8 && nbs <= c->npartial) {
+        const dim3 grid(nbs), block(MEAS_BLOCK);
+        if (c->p.group == 3) hipLaunchKernelGGL((k_polyakov_split<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nbs, c->loops);
+        else hipLaunchKernelGGL((k_polyakov_split<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, nbs, c->loops);
+        HIP_TRY(hipGetLastError());
+        *nb = nbs;
+        return QCD_OK;
+    }
+    *nb = cdiv(n3, MEAS_BLOCK);
+    const dim3 grid(*nb), block(MEAS_BLOCK);
+    if (c->p.group == 3) hipLaunchKernelGGL((k_polyakov<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, *nb, c->loops);
+    else hipLaunchKernelGGL((k_polyakov<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, c->g, c->partial, *nb, c->loops);
     HIP_TRY(hipGetLastError());
     return QCD_OK;
 }
@@ -1122,7 +1135,8 @@ static int measure_profile(qcd_ctx* c, int axis, double* sums, bool polyakov)
         if (nb > c->npartial || ext > c->partial_len || 2 * ext > c->result_len)
             return fail(QCD_ERR_UNSUPPORTED, "profile of %d planes does not fit the reduction buffers", ext);
         Timed tm(c, 1);
-        if (!c->loops_fresh && (rc = launch_polyakov(c, nb))) return rc;
+        int nb_used = 0;
+        if (!c->loops_fresh && (rc = launch_polyakov(c, &nb_used))) return rc;
         // one workgroup per plane: its pair is the plane's result and goes straight to the host's result words
         hipLaunchKernelGGL((k_loops_profile<MEAS_BLOCK>), dim3(ext), dim3(MEAS_BLOCK), 0, c->stream, c->loops, g, axis,
                            (double2*)c->result_host_dev);
@@ -1167,10 +1181,10 @@ int qcd_measure_polyakov_sums(qcd_ctx* c, double sums[4])
     if (rc) return rc;
     if (!sums) return fail(QCD_ERR_INVALID, "null output");
     const int n3 = c->g.nx * c->g.ny * c->g.nz;
-    const int nb = cdiv(n3, MEAS_BLOCK);
+    int nb = cdiv(n3, MEAS_BLOCK);
     if (nb > c->npartial) return fail(QCD_ERR_STATE, "partial buffer too small");
     Timed tm(c, 1);
-    if ((rc = launch_polyakov(c, nb))) return rc;
+    if ((rc = launch_polyakov(c, &nb))) return rc;
     if ((rc = tm.finish())) return rc;
     if ((rc = reduce_partials(c, nb, 2, sums))) return rc;
     c->loops_fresh = true;

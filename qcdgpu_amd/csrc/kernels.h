@@ -1845,6 +1845,72 @@ __global__ __launch_bounds__(BLOCK) void k_polyakov(const real2* __restrict__ U,
     block_reduce_store<BLOCK>(p2, p4, partial + nblocks);
 }
 
+// The same with a line cut into four segments: wavefront q of a workgroup multiplies the links t in [q * ceil(Nt/4), ...) of the
+// workgroup's 64 space sites (coalesced as before, four times the threads and requests in flight: one thread per line leaves
+// half the SIMDs of the device without a wavefront at 32^3 space sites), hands its partial product over through LDS, and wavefront 0
+// multiplies the four in order.  P is the same product in another grouping: equal to the kernel above to rounding.
+template <int GROUP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_polyakov_split(const real2* __restrict__ U, const Geom g,
+                                                          double2* __restrict__ partial, const int nblocks,
+                                                          double2* __restrict__ loops)
+{
+    constexpr int SITES = BLOCK / 4;
+    __shared__ real2 part[3][GROUP * GROUP][SITES];
+    const int q = (int)threadIdx.x / SITES, ls = (int)threadIdx.x % SITES;
+    const int t = blockIdx.x * SITES + ls;
+    const int n3 = g.nx * g.ny * g.nz;
+    const int len = (g.nt + 3) / 4;
+    const int t0 = q * len, t1 = (t0 + len < g.nt) ? t0 + len : g.nt;
+    mat<GROUP> m = unity<GROUP>();
+    if (t < n3 && t0 < t1) {
+        Site x;
+        x.xs = t / (g.ny * g.nz);
+        const int r = t - x.xs * (g.ny * g.nz);
+        x.z = r / g.ny;
+        x.y = r - x.z * g.ny;
+        x.t = t0;
+        m = load_site_link<GROUP>(U, g, 3, x);
+        for (int tt = t0 + 1; tt < t1; tt += 4) {
+            mat<GROUP> l[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x.t = (tt + k < t1) ? tt + k : t1 - 1;
+                l[k] = load_site_link<GROUP>(U, g, 3, x);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (tt + k < t1) m = mul(m, l[k]);
+        }
+    }
+    if (q > 0) {
+#pragma unroll
+        for (int k = 0; k < GROUP * GROUP; k++) part[q - 1][k][ls] = make_real2(m.e[k / GROUP][k % GROUP].re, m.e[k / GROUP][k % GROUP].im);
+    }
+    __syncthreads();
+    double re = 0.0, im = 0.0, p2 = 0.0, p4 = 0.0;
+    if (q == 0 && t < n3) {
+#pragma unroll 1
+        for (int s = 0; s < 3; s++) {
+            mat<GROUP> l;
+#pragma unroll
+            for (int k = 0; k < GROUP * GROUP; k++) {
+                const real2 v = part[s][k][ls];
+                l.e[k / GROUP][k % GROUP] = mk(v.x, v.y);
+            }
+            m = mul(m, l);
+        }
+        const cplx tr = trace(m);
+        re = tr.re;
+        im = tr.im;
+        p2 = re * re + im * im;
+        p4 = p2 * p2;
+        loops[t] = make_double2(re, im);
+    }
+    block_reduce_store<BLOCK>(re, im, partial);
+    __syncthreads();
+    block_reduce_store<BLOCK>(p2, p4, partial + nblocks);
+}
+
 // ---------------------------------------------------------------------------------------------
 // F_mu_nu traces (kernel lattice_measurement_plq with FMUNU / F0MU, SU(N)/suncl/sun_measurements_cl.cl:712-1175;
 // lattice_retrace_plaquette3_F, SU(N)/suncl/su3_measurements_cl.cl:550-589; CPU twin
