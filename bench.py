@@ -105,6 +105,29 @@ def checker_fixture(L, beta):
         return None
 
 
+def reference_chain(L, beta):
+    """Mean and binned error of Plq_total over the thermalised samples of the reference program's chain at this size
+    (tests/golden/stat_*.json, minted by oracle/make_golden_stat.py), or None."""
+    if len(set(L)) != 1 or beta != 6.0:
+        return None
+    name = "stat_su3_%dx%dx%dx%d_b6" % tuple(L)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", name + ".json")) as f:
+            doc = json.load(f)
+        x = doc["plq_total"][:500]
+        nav = int(doc["init"]["NAV"])
+    except Exception:  # noqa: BLE001
+        return None
+    nb = 10
+    per = len(x) // nb
+    if per < 2:
+        return None
+    bins = [sum(x[i * per:(i + 1) * per]) / per for i in range(nb)]
+    m = sum(x[:nb * per]) / (nb * per)
+    err = (sum((b - m) ** 2 for b in bins) / (nb - 1) / nb) ** 0.5
+    return {"name": name, "mean": m, "err": err, "n": nb * per, "nav": nav}
+
+
 def launch_ranks(n):
     """WORLD_SIZE unset and --gpus n > 1: start the n ranks as children of this process (which has
     not touched the GPU), pass rank 0's JSON line through and return the launcher's exit code."""
@@ -328,6 +351,32 @@ def main():
                      "avg_launch_us": 1e6 * per_launch_s,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
+    if world == 1:
+        # the chain's mean plaquette beside the mean of the reference program's own chain at this size (a committed fixture:
+        # different random streams, the same Markov kernel and start), outside the timed region
+        chain = reference_chain(L, args.beta)
+        if chain is not None:
+            # the same window of the chain as the fixture's: cold start, the fixture's thermalisation sweeps, then one
+            # measurement per sweep (from a cold start the plaquette is still settling after hundreds of sweeps, so the two
+            # means are compared over the same sweeps, not over any thermalised stretch)
+            with q.Context(group=3, L=L, beta=args.beta, device=local_rank, **kw) as c2:
+                c2.init_lattice()
+                c2.sweep(chain["nav"])
+                mine = []
+                for _ in range(chain["n"]):
+                    c2.sweep(1)
+                    mine.append(c2.plaquette()[2])
+            per = len(mine) // 10
+            bins = [sum(mine[i * per:(i + 1) * per]) / per for i in range(10)]
+            m_gpu = sum(mine[:10 * per]) / (10 * per)
+            e_gpu = (sum((b - m_gpu) ** 2 for b in bins) / 9.0 / 10.0) ** 0.5
+            sigma = (e_gpu ** 2 + chain["err"] ** 2) ** 0.5
+            result["mean_plaquette"]["reference_chain"] = {
+                "fixture": chain["name"], "sweeps": "%d..%d from the cold start, one sample per sweep" % (chain["nav"] + 1, chain["nav"] + chain["n"]),
+                "reference_mean": chain["mean"], "reference_err": chain["err"], "gpu_mean": m_gpu, "gpu_err": e_gpu,
+                "difference_in_sigma": abs(m_gpu - chain["mean"]) / sigma, "ok": bool(abs(m_gpu - chain["mean"]) < 4.0 * sigma)}
+            log("mean plaquette over sweeps %d..%d: %.6f +- %.6f, reference chain %.6f +- %.6f"
+                % (chain["nav"] + 1, chain["nav"] + chain["n"], m_gpu, e_gpu, chain["mean"], chain["err"]))
     if world == 1 and not args.no_cpu:
         # the scalar-model configuration beside the headline workload (not part of `value`): the O(N)
         # scalar model, 64^4 in single precision, NHIT = 10, site updates per second from HIP events

@@ -21,6 +21,9 @@ CASES = {
     # the benchmark's 16^4 lattice: 500 samples
     "stat_su3_16x16x16x16_b6": dict(GROUP=3, ND=4, LS=16, LT=16, BETA=6.0, NHIT=10, INTS=1,
                                     PRNG="RANLUX3", RANDSERIES=54, NAV=100, ITER=501, NITER=1),
+    # the benchmark's 32^4 lattice: 150 samples (more than an hour of the reference's program on one core)
+    "stat_su3_32x32x32x32_b6": dict(GROUP=3, ND=4, LS=32, LT=32, BETA=6.0, NHIT=10, INTS=1,
+                                    PRNG="RANLUX3", RANDSERIES=54, NAV=100, ITER=151, NITER=1),
 }
 
 
