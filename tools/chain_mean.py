@@ -18,7 +18,9 @@ def binned(x, size):
     return b.std(ddof=1) / np.sqrt(nb)
 
 
-for n, therm, samples in ((8, 200, 20000), (16, 200, 10000)):
+for n, therm, samples in ((8, 200, 20000), (16, 200, 10000), (32, 200, 4000)):
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", "stat_su3_%dx%dx%dx%d_b6.json" % (n, n, n, n))):
+        continue
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "stat_su3_%dx%dx%dx%d_b6.json" % (n, n, n, n))))
     ref = np.asarray(fx["plq_total"])
     print("reference %d^4: %d samples, mean %.6f, error by bins of 10/25/50: %.2e %.2e %.2e; first/second half %.6f %.6f"
