@@ -92,12 +92,12 @@ def measured_traffic(key="hbm_bytes_per_update_launch"):
     return None
 
 
-def checker_fixture(L, beta):
-    """Plaquette after sweeps 1 and 2 of the CPU checker's per-thread-stream mode at this size
-    (tests/golden/, minted by oracle/make_golden_persite32.py), or None."""
+def checker_fixture(L, beta, share):
+    """Plaquette after sweeps 1 and 2 of the CPU checker's per-thread-stream mode at this size, `share` sites of one
+    parity per stream (tests/golden/, minted by oracle/make_golden_persite32.py), or None."""
     if tuple(L) != (32, 32, 32, 32) or beta != 6.0:
         return None
-    p = os.path.join(ROOT, "tests", "golden", "persite_su3_32x32x32x32_b6.json")
+    p = os.path.join(ROOT, "tests", "golden", "persite_su3_32x32x32x32_b6%s.json" % ("_share%d" % share if share > 1 else ""))
     try:
         with open(p) as f:
             return json.load(f)
@@ -259,7 +259,7 @@ def main():
 
     # the first two sweeps from the cold start are compared with the CPU checker's numbers for the
     # same lattice, seed and stream layout (a committed fixture; they are part of the warm-up)
-    fixture = checker_fixture(L, args.beta) if world == 1 else None
+    fixture = checker_fixture(L, args.beta, ctx.rng_share) if world == 1 else None
     parity_check = None
     done = 0
     if fixture is not None and args.warmup >= 2:
@@ -335,7 +335,7 @@ def main():
         "data": "synthetic (cold start, beta=%.2f Markov chain, RANLUX3 per-thread streams, seed 54)" % args.beta,
         "config": {"workload": "SU(3) %dx%dx%dx%d heat-bath sweep (NHIT=10, re-unitarised), %d^4 per GPU"
                                % (L + (n,)), "lattice": list(L), "beta": args.beta, "nhit": 10,
-                   "prng": "RANLUX3", "parallelism": "x-slabs x%d" % world,
+                   "prng": "RANLUX3", "rng_share": ctx.rng_share, "parallelism": "x-slabs x%d" % world,
                    "halo_transport": None if world == 1 else ("RCCL send/recv issued by the C library (qcd_ring)" if transport == "ring"
                                                               else "torch.distributed P2P, backend %s" % backend)},
         "mean_plaquette": {"Plq_spat": plq[0], "Plq_temp": plq[1], "Plq_total": plq[2],

@@ -62,6 +62,14 @@ typedef struct {
                               (su3_matrix_memory.cl:57-98, su3cpu.cpp:165-197), diag(e^{i phi/2}, e^{-i phi/2}) for SU(2)
                               (su2_matrix_memory.cl:63-88); an updated link is stored as it comes out of the heat-bath
                               (suncl.cl:525-536), re-unitarisation and the link tables see the stored values.  halo = 0 only. */
+    int      rng_share;    /* sites of one parity per RANLUX stream: 1, 2 or 4; 0 = chosen from the FULL lattice (4 or 2 when
+                              it is large enough to keep the device busy with that many fewer independent streams, else 1).
+                              The sites (x, y-pair, z, t + k Nt/rng_share), k = 0 .. rng_share-1, are updated by one lane one
+                              after the other from one stream, whose state then travels once per pass instead of rng_share
+                              times.  The reference's device generator likewise serves many sites per instance
+                              (prns[thread + trial * PRNGSTEP], SU(N)/suncl/su3_update_cl.cl:597-649 with PRNG_instances
+                              streams, SU(N)/random/random.cpp:216-223).  The map is a function of global coordinates: every
+                              part of a cut lattice must be given the same value (0 in all of them does).  Nt % rng_share = 0. */
 } qcd_params;
 
 typedef struct {

@@ -704,6 +704,28 @@ void qo_staple2(const qo_lattice *lat, int gid, int dir, qo_su2 *out)
     *out = stap;
 }
 
+/* stream i seeded like instance i of the reference's device generator: instance 0 takes the CPU generator's seed,
+ * instance i the next rand() (SU(N)/random/random.cpp:462-465) */
+static void make_streams(qo_lattice *lat)
+{
+    qo_glibc_rand g;
+    qo_srand(&g, lat->randseries);
+    const int jseed = qo_rand(&g) % 2147483647;
+    const int ns = lat->sites / 2 / lat->share;
+    free(lat->streams);
+    lat->streams = (qo_ranlux *)calloc((size_t)ns, sizeof(qo_ranlux));
+    qo_ranlux_init(&lat->streams[0], jseed, lat->nskip);
+    for (int i = 1; i < ns; i++) qo_ranlux_init(&lat->streams[i], qo_rand(&g), lat->nskip);
+}
+/* the stream of half-site i (= gid / 2: y-pair fastest, then z, t, x) */
+static int stream_of_half_site(const qo_lattice *lat, int i)
+{
+    if (lat->share <= 1) return i;
+    const int nyh = lat->L[1] / 2, nz = lat->L[2], nt = lat->L[3], tq = nt / lat->share;
+    const int yh = i % nyh, z = (i / nyh) % nz, t = (i / (nyh * nz)) % nt, x = i / (nyh * nz * nt);
+    return ((x * tq + t % tq) * nz + z) * nyh + yh;
+}
+
 void qo_update_pass(qo_lattice *lat, int parity, int dir)
 {
     /* lattice_update_even / lattice_update_odd :79-117 */
@@ -713,7 +735,7 @@ void qo_update_pass(qo_lattice *lat, int parity, int dir)
     twist_begin(lat);
     for (int i = 0; i < lat->sites / 2; i++) {
         int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
-        qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[i] : &lat->seq;
+        qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[stream_of_half_site(lat, i)] : &lat->seq;
         if (lat->rng_mode == QO_RNG_PERSITE) qo_ranlux_align(rng);
         if (lat->group == 3) {
             qo_su3 *tab = (qo_su3 *)lat->links;
@@ -744,7 +766,7 @@ void qo_update_pass_range(qo_lattice *lat, int parity, int dir, int x_begin, int
     const int slice = lat->L[1] * lat->L[2] * lat->L[3];
     for (int i = x_begin * slice / 2; i < x_end * slice / 2; i++) {
         int gid = parity ? (int)qo_odd_gid(lat->L, (unsigned)i) : (int)qo_even_gid(lat->L, (unsigned)i);
-        qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[i] : &lat->seq;
+        qo_ranlux *rng = (lat->rng_mode == QO_RNG_PERSITE) ? &lat->streams[stream_of_half_site(lat, i)] : &lat->seq;
         if (lat->rng_mode == QO_RNG_PERSITE) qo_ranlux_align(rng);
         if (lat->group == 3) {
             qo_su3 *tab = (qo_su3 *)lat->links;
@@ -1196,13 +1218,21 @@ qo_lattice *qo_create(int group, const int L[4], double beta, int nhit, int ints
     qo_srand(&g, randseries);
     int jseed = qo_rand(&g) % 2147483647;
     qo_ranlux_init(&lat->seq, jseed, lat->nskip);
-    if (rng_mode == QO_RNG_PERSITE) {
-        int ns = lat->sites / 2;
-        lat->streams = (qo_ranlux *)calloc((size_t)ns, sizeof(qo_ranlux));
-        qo_ranlux_init(&lat->streams[0], jseed, lat->nskip);
-        for (int i = 1; i < ns; i++) qo_ranlux_init(&lat->streams[i], qo_rand(&g), lat->nskip);
-    }
+    lat->share = 1;
+    if (rng_mode == QO_RNG_PERSITE) make_streams(lat);
     return lat;
+}
+
+/* Per-thread streams shared by `share` sites of one parity: the half-sites (x, t' + k Nt/share, z, y-pair),
+ * k = 0 .. share-1, use stream ((x Nt/share + t') Nz + z) Ny/2 + y-pair one after the other in every pass and in
+ * the hot start (a device lane that updates them in turn moves the generator state once).  Call before the first
+ * random number is drawn (before qo_init_links for a hot start).  share must divide Nt. */
+int qo_set_rng_share(qo_lattice *lat, int share)
+{
+    if (share < 1 || lat->L[3] % share) return -1;
+    lat->share = share;
+    if (lat->rng_mode == QO_RNG_PERSITE) make_streams(lat);
+    return 0;
 }
 
 void qo_destroy(qo_lattice *lat)
@@ -1280,7 +1310,7 @@ static void init_hot_persite(qo_lattice *lat)
     const int nd = lat->nd, per_link = (lat->group == 3) ? 12 : 4;
     for (int dir = 0; dir < nd; dir++)
         for (int h = 0; h < lat->sites / 2; h++) {
-            qo_ranlux *rng = &lat->streams[h];
+            qo_ranlux *rng = &lat->streams[stream_of_half_site(lat, h)];
             qo_ranlux_align(rng);
             for (int s = 0; s < 2; s++) {
                 float r[12];

@@ -54,13 +54,14 @@ typedef struct {
     unsigned randseries;
     void *links;          /* qo_su3[nd*sites] or qo_su2[nd*sites], index gid*nd+dir */
     qo_ranlux seq;        /* the one sequential stream */
-    qo_ranlux *streams;   /* sites/2 streams in QO_RNG_PERSITE mode */
+    qo_ranlux *streams;   /* sites/2/share streams in QO_RNG_PERSITE mode */
     unsigned long long rng_draws; /* numbers consumed (all modes but gid) */
     /* twisted boundary condition (device path and CPU re-measurement of the reference only; its sequential CPU
      * program has none): see qo_set_twist */
     double phi, omega;
     void *tw_backup;      /* the stored U_y links of the slice x = Nx-1 while the table holds their twisted form */
     int tw_depth;
+    int share;            /* sites of one parity per stream in QO_RNG_PERSITE mode (qo_set_rng_share), 1 by default */
 } qo_lattice;
 
 /* glibc rand() restated (TYPE_3 additive feedback), so that seeds do not depend on the libc */
@@ -101,6 +102,8 @@ void   qo_hot_link2(qo_su2 *m, const float r[4]);
  * returns it, without taking the twist off (SU(N)/suncl/suncl.cl:525-536).  Measurements: pinned by the reference's CPU
  * re-measurement; update pass: device only in the reference, "parity unpinned". */
 void qo_set_twist(qo_lattice *lat, double phi, double omega);
+/* per-thread streams shared by `share` sites of one parity (Nt/share apart in t); before any number is drawn; 0 = ok */
+int  qo_set_rng_share(qo_lattice *lat, int share);
 
 /* lattice life cycle */
 qo_lattice *qo_create(int group, const int L[4], double beta, int nhit, int ints,

@@ -26,7 +26,8 @@ class Params(C.Structure):
     _fields_ = [("group", C.c_int), ("nd", C.c_int), ("L", C.c_int * 4), ("precision", C.c_int),
                 ("beta", C.c_double), ("nhit", C.c_int), ("start_mode", C.c_int),
                 ("lux_level", C.c_int), ("rand_series", C.c_uint), ("device", C.c_int),
-                ("x0", C.c_int), ("nx_local", C.c_int), ("halo", C.c_int), ("phi", C.c_double), ("omega", C.c_double)]
+                ("x0", C.c_int), ("nx_local", C.c_int), ("halo", C.c_int), ("phi", C.c_double), ("omega", C.c_double),
+                ("rng_share", C.c_int)]
 
 
 class OnParams(C.Structure):
@@ -176,10 +177,11 @@ class Context:
     """One x-slab of the lattice on one device (qcd_ctx)."""
 
     def __init__(self, group, L, beta, nhit=10, start_mode=START_COLD, lux_level=3, rand_series=54,
-                 device=0, x0=0, nx_local=None, halo=0, precision=2, phi=0.0, omega=0.0):
+                 device=0, x0=0, nx_local=None, halo=0, precision=2, phi=0.0, omega=0.0, rng_share=0):
         self.params = Params()
         p = self.params
         p.phi, p.omega = phi, omega
+        p.rng_share = rng_share   # sites per RANLUX stream: 0 = the library's choice from the full lattice
         p.group, p.nd, p.precision = group, 4, precision
         for i in range(4):
             p.L[i] = L[i]
@@ -198,6 +200,13 @@ class Context:
 
     def _check(self, rc):
         _check(rc, self.lib)
+
+    @property
+    def rng_share(self):
+        """Sites of one parity per RANLUX stream, as the library resolved it (qcd_params.rng_share)."""
+        p = Params()
+        self._check(self.lib.qcd_get_params(self.h, C.byref(p)))
+        return p.rng_share
 
     def close(self):
         if getattr(self, "h", None):

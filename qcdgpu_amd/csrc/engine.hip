@@ -178,12 +178,13 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     g.ux0 = xs_begin;
     g.unx = xs_count;
     const int regions = g.nzr * g.ntr;
-    const int nblocks = regions * (int)cdiv((long)g.unx * g.region_h, UPD_BLOCK);
+    const int ngroups = regions * (int)cdiv((long)g.unx * g.region_h, UPD_BLOCK);   // groups of `share` blocks (Geom::share)
+    const int nblocks = ngroups * g.share;
     // launch no more workgroups than the device holds at one time and let each walk several
-    // blocks of sites: a finished wave goes straight on to its next site instead of waiting for
+    // groups of blocks: a finished wave goes straight on to its next site instead of waiting for
     // its stores to drain and for the dispatcher to start a successor
-    int nwg = nblocks;
-    if (c->upd_grid > 0 && c->upd_grid < nblocks) nwg = c->upd_grid;
+    int nwg = ngroups;
+    if (c->upd_grid > 0 && c->upd_grid < ngroups) nwg = c->upd_grid;
     const dim3 grid(nwg), block(UPD_BLOCK);
     const double beta_eff = c->p.beta / c->p.group;  // SU(N)/suncpp/Update/sun_update.h:94
     UpdArgs a;
@@ -206,6 +207,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     a.gidr = c->gidr;
     a.draws = c->draws_dev;
     a.nblocks = nblocks;
+    a.ngroups = ngroups;
     a.phase = -1;
     a.reverse = 0;
     a.edge_local = 0;
@@ -238,14 +240,16 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
     if constexpr (GROUP == 3 && !GID && UPD_BLOCK == 64) {
         // it has no code for partly filled blocks
         const bool full = ((long)g.unx * g.region_h) % UPD_BLOCK == 0 && g.tz == 0;
-        if (c->gh_grid > 0 && full && (c->gh_mode == 2 || (c->gh_mode == 1 && nblocks >= 2 * GH_SIDE * c->gh_grid))) {
+        // (shared streams need the kernel's teams to be pairs of wavefronts: a heat-bath wavefront then takes every block of its team)
+        if (c->gh_grid > 0 && full && (g.share == 1 || GH_TEAMS == GH_SIDE) &&
+            (c->gh_mode == 2 || (c->gh_mode == 1 && nblocks >= 2 * GH_SIDE * c->gh_grid && ngroups >= GH_SIDE * c->gh_grid))) {
             paired = true;
             if (edge_slices > 0) {
                 // the launch starts at the last `edge_slices` slices and wraps to the first ones: with
                 // whole blocks per slice the first blocks of every region are exactly those slices
                 if (g.region_h % UPD_BLOCK != 0 || !c->edge_count)
                     return fail(QCD_ERR_UNSUPPORTED, "edge signal: a slice of this lattice is not a whole number of blocks per region");
-                a.edge_local = 2 * edge_slices * (int)(g.region_h / UPD_BLOCK);
+                a.edge_local = 2 * edge_slices * (int)(g.region_h / UPD_BLOCK) * g.share;
                 a.edge_total = (unsigned)a.edge_local * (unsigned)regions;
                 a.edge_seq = c->edge_sig.seq;
                 a.edge_count = c->edge_count;
@@ -288,7 +292,7 @@ template <int GROUP>
 int launch_overrelax(qcd_ctx* c, int parity, int dir)
 {
     const Geom& g = c->g;
-    const dim3 grid(g.nzr * g.ntr * cdiv((long)g.nx * g.region_h, UPD_BLOCK)), block(UPD_BLOCK);
+    const dim3 grid(g.nzr * g.ntr * cdiv((long)g.nx * g.region_h, UPD_BLOCK) * g.share), block(UPD_BLOCK);
     if (g.odd) {
         const int nph = 1 + ((g.odd & 1) && dir != 0) + ((g.odd & 4) && dir != 2) + ((g.odd & 8) && dir != 3);
         for (int ph = 0; ph < nph; ph++) switch (dir) {
@@ -439,11 +443,11 @@ int upload_gid_slices(qcd_ctx* c, int gx0, int slice0, int nslices)
 int seed_streams(qcd_ctx* c)
 {
     const Geom& g = c->g;
-    const int ns = g.vh_int;
+    const int ns = c->rv.ns;
     const int nskip = rlx_nskip_for_level(c->p.lux_level);
-    // stream index = GLOBAL half index of the thread's site pair: results do not depend on how
-    // the lattice is cut into slabs
-    const long first = (long)c->p.x0 * g.slice_h;
+    // stream index = GLOBAL number of the stream (stream_of with the global x; with share = 1 the global half
+    // index of the thread's site pair): results do not depend on how the lattice is cut into slabs
+    const long first = (long)c->p.x0 * (g.slice_h / g.share);
     std::vector<int> seeds = stream_seeds(c->p.rand_series, first, ns);
     std::vector<unsigned> st((size_t)RLX_SLOT_WORDS * ns);
     for (int i = 0; i < ns; i++) {
@@ -534,6 +538,10 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
                     p->L[1], p->L[2], p->L[3]);
     if ((p->phi != 0.0 || p->omega != 0.0) && (p->halo || ((p->L[0] | p->L[2] | p->L[3]) & 1)))
         return fail(QCD_ERR_UNSUPPORTED, "twisted boundary conditions (PHI, OMEGA) are supported for one uncut lattice with even extents only");
+    if (p->rng_share != 0 && p->rng_share != 1 && p->rng_share != 2 && p->rng_share != 4)
+        return fail(QCD_ERR_INVALID, "rng_share = %d is not 0 (automatic), 1, 2 or 4", p->rng_share);
+    if (p->rng_share > 1 && p->L[3] % p->rng_share)
+        return fail(QCD_ERR_INVALID, "rng_share = %d does not divide Nt = %d", p->rng_share, p->L[3]);
     if (p->nhit < 1) return fail(QCD_ERR_INVALID, "NHIT = %d < 1", p->nhit);
     if (p->lux_level < 0 || p->lux_level > 4) return fail(QCD_ERR_INVALID, "RANLUX level %d not in 0..4", p->lux_level);
     if (p->rand_series == 0) return fail(QCD_ERR_INVALID, "RANDSERIES = 0 (time seed) must be resolved by the host");
@@ -586,37 +594,56 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
         g.tw[0] = cos(t1); g.tw[1] = sin(t1);
         g.tw[2] = cos(t2); g.tw[3] = sin(t2);
     }
+    // Sites per random stream (qcd_params::rng_share).  Automatic: a function of the FULL lattice only, so that the
+    // parts of a cut lattice agree.  Sharing divides the number of independent units of work of a pass, so it is for
+    // lattices whose pass keeps the device busy even then: at least 2048 groups of 64 sites per pass.
+    g.share = p->rng_share;
+    if (g.share == 0) {
+        const long blocks = sites / 2 / 64;
+        g.share = 1;
+        if (!g.odd) {
+            if (p->L[3] % 4 == 0 && blocks / 4 >= 2048) g.share = 4;
+            else if (p->L[3] % 2 == 0 && blocks / 2 >= 2048) g.share = 2;
+        }
+        if (const char* ov = getenv("QCDGPU_AMD_SHARE")) {   // diagnostic override of the automatic choice
+            const int v = atoi(ov);
+            if ((v == 1 || v == 2 || v == 4) && p->L[3] % v == 0) g.share = v;
+        }
+        c->p.rng_share = g.share;
+    }
+    g.tq = g.nt / g.share;
     // (z,t) regions for the 8 XCDs: the split with the smallest cut surface that divides both
-    // extents; none -> one region (plain linear order)
+    // extents; none -> one region (plain linear order).  With shared streams the plane that is cut is (z, t mod tq),
+    // and its t extent is a cut in any case (t = tq - 1 and t = tq belong to different members of a group)
     g.nzr = g.ntr = 1;
     if (!getenv("QCDGPU_AMD_LINEAR_ORDER")) {  // diagnostic switch: plain linear workgroup order
         static const int cand[4][2] = {{2, 4}, {4, 2}, {1, 8}, {8, 1}};
         double best = 1e30;
         for (auto& cd : cand) {
-            if (g.nz % cd[0] || g.nt % cd[1]) continue;
-            const int rz = g.nz / cd[0], rt = g.nt / cd[1];
+            if (g.nz % cd[0] || g.tq % cd[1]) continue;
+            const int rz = g.nz / cd[0], rt = g.tq / cd[1];
             // fraction of a region's sites that sit on a cut face
-            const double cut = (cd[0] > 1 ? 1.0 / rz : 0.0) + (cd[1] > 1 ? 1.0 / rt : 0.0);
+            const double cut = (cd[0] > 1 ? 1.0 / rz : 0.0) + ((cd[1] > 1 || g.share > 1) ? 1.0 / rt : 0.0);
             if (cut < best) { best = cut; g.nzr = cd[0]; g.ntr = cd[1]; }
         }
     }
     if (const char* ov = getenv("QCDGPU_AMD_REGIONS")) {  // diagnostic override "nzr,ntr"
         int a = 0, b = 0;
-        if (sscanf(ov, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && g.nz % a == 0 && g.nt % b == 0) {
+        if (sscanf(ov, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && g.nz % a == 0 && g.tq % b == 0) {
             g.nzr = a;
             g.ntr = b;
         }
     }
     g.rz = g.nz / g.nzr;
-    g.rt = g.nt / g.ntr;
-    g.region_h = g.nyh * g.rz * g.rt;
+    g.rt = g.tq / g.ntr;
+    g.region_h = g.nyh * g.rz * g.rt;   // half-sites of a region per x slice and group member
     g.tz = g.tt = g.tx = 0;
     g.ux0 = 0;
     g.unx = g.nx;
     if (const char* ov = getenv("QCDGPU_AMD_TILE")) {  // diagnostic override "tz,tt,tx"
         int a = 0, b = 0, d = 0;
         if (sscanf(ov, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0 && UPD_BLOCK % g.nyh == 0 &&
-            a * b * d == UPD_BLOCK / g.nyh && g.rz % a == 0 && g.rt % b == 0 && g.nx % d == 0) {
+            a * b * d == UPD_BLOCK / g.nyh && g.rz % a == 0 && g.rt % b == 0 && g.nx % d == 0 && g.share == 1) {
             g.tz = a;
             g.tt = b;
             g.tx = d;
@@ -661,12 +688,13 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     tryhip(hipEventCreate(&c->ev0), "hipEventCreate");
     tryhip(hipEventCreate(&c->ev1), "hipEventCreate");
     tryhip(hipMalloc(&c->U, c->U_elems * sizeof(real2)), "hipMalloc(links)");
-    const size_t stw = (size_t)RLX_SLOT_WORDS * g.vh_int * sizeof(unsigned);
+    const size_t nstreams = (size_t)g.vh_int / g.share;
+    const size_t stw = (size_t)RLX_SLOT_WORDS * nstreams * sizeof(unsigned);
     tryhip(hipMalloc(&c->rv.slot0, 2 * stw), "hipMalloc(ranlux)");   // both slots, back to back
-    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_SLOT_WORDS * g.vh_int : nullptr;
+    c->rv.slot1 = c->rv.slot0 ? c->rv.slot0 + (size_t)RLX_SLOT_WORDS * nstreams : nullptr;
     c->slice_slot = (unsigned char*)calloc((size_t)g.nx, 1);
     if (!c->slice_slot && rc == QCD_OK) rc = fail(QCD_ERR_NOMEM, "calloc(slice slots)");
-    c->rv.ns = g.vh_int;
+    c->rv.ns = (int)nstreams;
     if (p->start_mode == QCD_START_GID)
         tryhip(hipMalloc(&c->gidr, (size_t)6 * g.nx * g.gslice * sizeof(float)), "hipMalloc(gid table)");
     // the profile measurements need one pair per plane and up to 64 partials per plane
@@ -795,7 +823,7 @@ int qcd_init_lattice(qcd_ctx* c)
     rc = seed_streams(c);
     if (rc) return rc;
     if (c->p.start_mode == QCD_START_HOT) {
-        const dim3 grid(cdiv((long)g.vh_int, MEAS_BLOCK)), block(MEAS_BLOCK);
+        const dim3 grid(cdiv((long)c->rv.ns, MEAS_BLOCK)), block(MEAS_BLOCK);
         if (c->p.group == 3) hipLaunchKernelGGL((k_init_hot<3, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, c->rv, c->draws_dev);
         else hipLaunchKernelGGL((k_init_hot<2, MEAS_BLOCK>), grid, block, 0, c->stream, c->U, g, c->rv, c->draws_dev);
         HIP_TRY(hipGetLastError());
@@ -1261,7 +1289,7 @@ int qcd_download(qcd_ctx* c, void* host_table, size_t bytes, int rowsize)
 size_t qcd_rng_state_bytes(const qcd_ctx* c)
 {
     if (!c) return 0;
-    return sizeof(unsigned long long) + (size_t)(2 * RLX_STATE_WORDS + 1) * c->g.vh_int * sizeof(unsigned);
+    return sizeof(unsigned long long) + (size_t)(2 * RLX_STATE_WORDS + 1) * (size_t)c->rv.ns * sizeof(unsigned);
 }
 
 static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
@@ -1272,7 +1300,7 @@ static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
     if (bytes != qcd_rng_state_bytes(c)) return fail(QCD_ERR_INVALID, "generator state is %zu bytes, got %zu", qcd_rng_state_bytes(c), bytes);
     // the caller's format has the 24 words and the carry of a state one per 32-bit word; the device
     // keeps them packed (rlx_pack4): converted here
-    const size_t ns = (size_t)c->g.vh_int;
+    const size_t ns = (size_t)c->rv.ns;
     char* h = (char*)host;
     const hipMemcpyKind kind = up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
     auto cp = [&](void* dev, void* hp, size_t n) -> hipError_t {
@@ -1292,7 +1320,7 @@ static int rng_state_copy(qcd_ctx* c, void* host, size_t bytes, bool up)
     // from that on the way out; on the way in each stream's current state goes to slot 0
     unsigned* ctlw = (unsigned*)h;
     if (!up)
-        for (size_t i = 0; i < ns; i++) ctlw[i] = c->slice_slot[i / (size_t)c->g.slice_h];
+        for (size_t i = 0; i < ns; i++) ctlw[i] = c->slice_slot[i / (size_t)(c->g.slice_h / c->g.share)];
     h += ns * sizeof(unsigned);
     std::vector<unsigned> packed((size_t)2 * RLX_SLOT_WORDS * ns);   // both slots, as on the device
     unsigned* wide = (unsigned*)h;                                   // [slot][w][stream], w in [0, 25)

@@ -157,6 +157,7 @@ void model::lattice_get_init_file(char* file)
         if (!strcmp(v, "OMEGA")) OMEGA = p.fVarVal;
         if (!strcmp(v, "NAV")) NAV = p.iVarVal;
         if (!strcmp(v, "NOVERRELAX")) NOVERRELAX = p.iVarVal;   // extension: the reference has no overrelaxation
+        if (!strcmp(v, "RNGSHARE")) RNGSHARE = p.iVarVal;       // extension: sites per RANLUX stream (qcd_params::rng_share)
         if (!strcmp(v, "INTS"))
             ints = (p.iVarVal == 0) ? model_start_hot : (p.iVarVal == 2 ? model_start_gid : model_start_cold);
         if (!strcmp(v, "RANDSERIES") && !p.ivVarVal.empty()) rnds = p.ivVarVal;
@@ -312,6 +313,7 @@ void model::lattice_init(void)
         p.precision = (int)precision_word();
         p.phi = PHI;
         p.omega = OMEGA;
+        p.rng_share = RNGSHARE;
         p.beta = BETA;
         p.nhit = NHIT;
         p.start_mode = (ints == model_start_hot) ? QCD_START_HOT : (ints == model_start_gid ? QCD_START_GID : QCD_START_COLD);

@@ -117,6 +117,7 @@ public:
     int NHIT = 10;
     int NHITPar = 1;
     int NOVERRELAX = 0;   // overrelaxation sweeps after every heat-bath sweep (not in the reference)
+    int RNGSHARE = 0;     // sites of one parity per RANLUX stream (1, 2, 4; 0: chosen by the library from the lattice size)
     double BETA = 6.5;
     double PHI = 0.0;
     double OMEGA = 0.0;

@@ -24,6 +24,10 @@ namespace qcd {
 constexpr int RLX_WINDOW = 2;
 // rows of a thread's LDS column: the window and four more, through which values beyond the window are handed out
 constexpr int RLX_ROWS = 24 * RLX_WINDOW + 4;
+// the pair kernel's columns have 25 rows more: the generator state in front of the second batch, for streams that go
+// on to another site in the same launch (Geom::share)
+constexpr int RLX_KEEP_ROW = RLX_ROWS;
+constexpr int RLX_ROWS_KEEP = RLX_ROWS + 25;
 
 // ---------------------------------------------------------------------------------------------
 // random sources of the heat-bath
@@ -101,7 +105,9 @@ struct RlxHome {
 // batch.  Slow (about a link update's worth of instructions per batch), small, without a call
 // and without registers of its own besides a rotation count and the carry; it runs for the few
 // lanes that need it, at small beta for many.
-template <int BLOCK, int NSKIP>
+// KEEP_LDS: where generate_keep leaves the state in front of the second batch (rows RLX_KEEP_ROW.. of the column, or
+// the caller's registers)
+template <int BLOCK, int NSKIP, bool KEEP_LDS = false>
 struct RlxFast {
     __device__ __forceinline__ void skip(RlxRegs& r) const
     {
@@ -113,6 +119,8 @@ struct RlxFast {
     int pos, cur;
     int rot;          // slow form: physical row of logical word k is (k + rot) mod 24
     unsigned carry;   // slow form: the generator's carry
+    bool is_kept;     // the state in front of the second batch is in `kept` / the column's keep rows, not in memory
+    RlxRegs kept;     // (KEEP_LDS = false) that state
 
     // The three steps of opening the stream, separate so that the kernel can place the state's
     // loads under other work:
@@ -125,6 +133,7 @@ struct RlxFast {
         cur = view.cur;
         rot = 0;
         carry = 0u;
+        is_kept = false;
     }
     // fetch: request the generator state in front of the stream's next batch
     __device__ __forceinline__ void fetch(RlxRegs& r) const
@@ -154,6 +163,84 @@ struct RlxFast {
         h.store_state(r, cur ^ 1);   // in front of the second batch: the usual next state
         rlx_batch(r, buf + 24 * BLOCK, BLOCK);
 #endif
+    }
+    // A stream that serves several sites of a launch (Geom::share) goes from one to the next without its state
+    // passing through memory.  generate_keep: like generate, but the state in front of the second batch -- where the
+    // stream resumes unless the second batch is touched -- is kept instead of stored.
+    __device__ __forceinline__ void generate_keep(RlxRegs& r)
+    {
+        rlx_batch(r, buf, BLOCK);
+        skip(r);
+        is_kept = true;
+        if (KEEP_LDS) {
+            unsigned* w = words();
+#pragma unroll
+            for (int k = 0; k < 24; k++) w[(RLX_KEEP_ROW + k) * BLOCK] = r.s[k];
+            w[(RLX_KEEP_ROW + 24) * BLOCK] = r.c;
+        } else {
+            kept = r;
+        }
+        rlx_batch(r, buf + 24 * BLOCK, BLOCK);
+    }
+    // after the update: the state in front of the stream's next batch into r (what close() leaves in memory)
+    __device__ __forceinline__ void carry_over(RlxRegs& r)
+    {
+        const unsigned* w = words();
+        if (pos > 24 * RLX_WINDOW) {
+            // the slow form keeps the state in front of the next batch in the column's first 24 rows, rotated
+#pragma unroll
+            for (int k = 0; k < 24; k++) {
+                int ph = k + rot;
+                ph = ph >= 24 ? ph - 24 : ph;
+                r.s[k] = w[ph * BLOCK];
+            }
+            r.c = carry;
+            return;
+        }
+        if (KEEP_LDS) {
+#pragma unroll
+            for (int k = 0; k < 24; k++) r.s[k] = w[(RLX_KEEP_ROW + k) * BLOCK];
+            r.c = w[(RLX_KEEP_ROW + 24) * BLOCK];
+        } else {
+            r = kept;
+        }
+        if (pos > 24) {   // the second batch was touched: the stream resumes in front of the third
+            rlx_round(r);
+            skip(r);
+        }
+    }
+    // a state from one site to the next through the column's first 25 rows (the window's values are spent by then)
+    __device__ __forceinline__ void park(const RlxRegs& r)
+    {
+        unsigned* w = words();
+#pragma unroll
+        for (int k = 0; k < 24; k++) w[k * BLOCK] = r.s[k];
+        w[24 * BLOCK] = r.c;
+    }
+    __device__ __forceinline__ void unpark(RlxRegs& r) const
+    {
+        const unsigned* w = words();
+#pragma unroll
+        for (int k = 0; k < 24; k++) r.s[k] = w[k * BLOCK];
+        r.c = w[24 * BLOCK];
+    }
+    // the stream for member `sub` of its sites in this launch (`last`: no member follows), and the end of that use
+    __device__ __forceinline__ void open_member(const RlxView& view, int stream, float* lds_column, int sub, bool last)
+    {
+        attach(view, stream, lds_column);
+        RlxRegs r;
+        if (sub == 0) fetch(r);
+        else unpark(r);
+        if (last) generate(r);
+        else generate_keep(r);
+    }
+    __device__ __forceinline__ int close_member(bool last)
+    {
+        if (last) return close();
+        RlxRegs r;
+        carry_over(r);
+        park(r);
+        return pos;
     }
     __device__ __forceinline__ void open(const RlxView& view, int stream, float* lds_column)
     {
@@ -189,8 +276,21 @@ struct RlxFast {
     __device__ __forceinline__ void slow_load()
     {
         typedef unsigned quad_t __attribute__((ext_vector_type(4)));
-        const quad_t* __restrict__ p = (const quad_t*)(h.s0 + (size_t)(cur ^ 1) * RLX_SLOT_WORDS * h.ns);
         unsigned* w = words();
+        if (is_kept) {   // a stream that goes on to another site: generate_keep kept that state out of memory
+            if (KEEP_LDS) {
+#pragma unroll 1
+                for (int k = 0; k < 24; k++) w[k * BLOCK] = w[(RLX_KEEP_ROW + k) * BLOCK];
+                carry = w[(RLX_KEEP_ROW + 24) * BLOCK];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 24; k++) w[k * BLOCK] = kept.s[k];
+                carry = kept.c;
+            }
+            rot = 0;
+            return;
+        }
+        const quad_t* __restrict__ p = (const quad_t*)(h.s0 + (size_t)(cur ^ 1) * RLX_SLOT_WORDS * h.ns);
         unsigned d[RLX_SLOT_WORDS];
 #pragma unroll
         for (int q4 = 0; q4 < RLX_PACKED_QUADS; q4++) {
@@ -951,7 +1051,9 @@ struct UpdArgs {
     RlxView rv;
     const float* gidr;
     unsigned long long* draws;
-    int nblocks;   // blocks of BLOCK sites in the pass; workgroup b takes b, b + gridDim.x, ...
+    int nblocks;   // blocks of BLOCK sites in the pass
+    int ngroups;   // nblocks / g.share: groups of blocks whose sites share their random streams, block after block;
+                   // workgroup b takes the groups b, b + gridDim.x, ...
     int phase;     // lattices with an odd extent: only the sites of this phase are updated (update_phase); else -1
     int reverse;   // pair kernel: walk the x-slices downwards (every other pass: the end of the pass before is what the
                    // memory-side cache still holds)
@@ -998,12 +1100,12 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     unsigned long long used = 0;
     (void)args_by_value;
     typedef const UpdArgs __attribute__((address_space(4))) * ArgPtr;
-    int wb = blockIdx.x;
+    int wg = blockIdx.x, sub = 0;   // group of blocks, member of the group
 #pragma unroll 1
     for (;;) {
     ArgPtr ap = (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ap));   // a fresh, opaque pointer every trip: nothing read through it is carried over
-    if (wb >= ap->nblocks) break;
+    if (wg >= ap->ngroups) break;
     real2* __restrict__ U = ap->U;
     Geom g;   // member by member: a whole-struct copy out of the argument segment goes through scratch
     g.nx = ap->g.nx; g.ny = ap->g.ny; g.nz = ap->g.nz; g.nt = ap->g.nt;
@@ -1011,7 +1113,9 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     g.vh_int = ap->g.vh_int; g.vh_alloc = ap->g.vh_alloc; g.gsites = ap->g.gsites; g.gslice = ap->g.gslice;
     g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h;
     g.tz = ap->g.tz; g.tt = ap->g.tt; g.tx = ap->g.tx;
-    g.ux0 = ap->g.ux0; g.unx = ap->g.unx; g.odd = ap->g.odd;
+    g.ux0 = ap->g.ux0; g.unx = ap->g.unx; g.odd = ap->g.odd; g.share = ap->g.share; g.tq = ap->g.tq;
+    const int wb = ((wg / (g.nzr * g.ntr)) * g.share + sub) * (g.nzr * g.ntr) + wg % (g.nzr * g.ntr);
+    const bool last = sub == g.share - 1;
     if (ANY) { g.tw[0] = ap->g.tw[0]; g.tw[1] = ap->g.tw[1]; g.tw[2] = ap->g.tw[2]; g.tw[3] = ap->g.tw[3]; }
     const int parity = ap->parity;
     const int nhit = ap->nhit;
@@ -1044,7 +1148,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
         if constexpr (ANY) {
             A = staple_any<GROUP, DIR>(U, g, x);
             Ul = load_site_link<GROUP>(U, g, DIR, x);   // twisted like every link that is read, stored as it comes out (suncl.cl:525-536)
-            if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
+            if (!GID) rs.open_member(rv, t, rbuf + threadIdx.x, sub, last);
         } else if constexpr (GROUP == 3) {
             // the stream's state is requested as soon as the staple's registers are free (requesting
             // state and link under the last staple term costs 40 registers and gains nothing)
@@ -1056,18 +1160,24 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
             RlxRegs r;
             staple_pipe_tail<DIR>(sp, U, g, hb, nbr, parity, NoHook());
             own = issue_link<(((nt_mask(DIR) >> 18) & 1u) ? AUX_NT : 0)>(r_own, g, hb);
-            if (!GID) rs.fetch(r);
+            if (!GID) {
+                if (sub == 0) rs.fetch(r);
+                else rs.unpark(r);
+            }
             A = sp.stap;
             QCD_STAMP(1);
             pin(own);
             Ul = as_su3(own);
             __builtin_amdgcn_s_setprio(QCD_PRIO_ALU);
-            if (!GID) rs.generate(r);
+            if (!GID) {
+                if (last) rs.generate(r);
+                else rs.generate_keep(r);
+            }
         } else {
             A = staple<GROUP, DIR>(U, g, hb, nbr, parity);
             QCD_STAMP(1);
             Ul = load_link_buf(r_own, g, hb, (mat<GROUP>*)nullptr);
-            if (!GID) rs.open(rv, t, rbuf + threadIdx.x);
+            if (!GID) rs.open_member(rv, t, rbuf + threadIdx.x, sub, last);
         }
         QCD_STAMP(2);
         if (GID) {
@@ -1083,7 +1193,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
         } else {
             update_link<false>(Ul, A, beta_eff, (real)ap->beta_inv, nhit, rs, fm);
             QCD_STAMP(3);
-            used += (unsigned long long)rs.close();
+            used += (unsigned long long)rs.close_member(last);
             store_link_buf(r_own, g, hb, Ul);
         }
         if (GID) store_link_buf(r_own, g, hb, Ul);
@@ -1095,7 +1205,12 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
         }
 #endif
     }
-    wb += gridDim.x;
+    if (last) {
+        sub = 0;
+        wg += gridDim.x;
+    } else {
+        sub++;
+    }
     }
     if (!GID) {
         used = block_sum_u64<BLOCK>(used);
@@ -1175,7 +1290,7 @@ template <int TEAMS>
 struct GhShared {
     static constexpr int PER = GH_SIDE / TEAMS;             // wavefronts of either kind per team
     real2 stap[TEAMS][GH_SLOTS][PER][9][64];              // partial staple sums: 18 reals per lane
-    float rbuf[GH_SIDE][RLX_ROWS * 64];              // random numbers of the heat-bath wavefronts
+    float rbuf[GH_SIDE][RLX_ROWS_KEEP * 64];         // random numbers of the heat-bath wavefronts, and a kept generator state
     double2 logtab[LOG_TABLE_ENTRIES];
     unsigned full_seq[TEAMS][GH_SLOTS][PER];                // gather wavefront j has put block (full_seq - 1) into the slot
     unsigned free_seq[TEAMS][GH_SLOTS];                     // the heat-bath side has read block (free_seq - 1) out of the slot
@@ -1183,17 +1298,21 @@ struct GhShared {
 };
 
 // the team's it-th block of sites: workgroup b works for region b % regions, the teams of the
-// workgroups of a region take consecutive blocks of it; < 0: no more blocks
-// reverse: the blocks of a region taken from the last x-slice down to the first (see UpdArgs::reverse)
+// workgroups of a region take consecutive groups of its blocks (the `share` blocks whose sites share their random
+// streams), one member after the other; < 0: no more blocks
+// reverse: the groups of a region taken from the last x-slice down to the first (see UpdArgs::reverse); the order
+// inside a group is the streams' order of use and stays
 template <int TEAMS>
 __device__ __forceinline__ int gh_block(const Geom& g, const int nblocks, const int team, const int it, const int reverse = 0)
 {
     const int regions = g.nzr * g.ntr;
     const int wgs = (int)gridDim.x / regions;
-    int local = (it * wgs + (int)blockIdx.x / regions) * TEAMS + team;
-    if ((int)blockIdx.x >= wgs * regions || local >= nblocks / regions) return -1;
-    if (reverse) local = nblocks / regions - 1 - local;
-    return local * regions + (int)blockIdx.x % regions;
+    const int grp_it = it / g.share;
+    const int ngroups = nblocks / regions / g.share;
+    int local = (grp_it * wgs + (int)blockIdx.x / regions) * TEAMS + team;
+    if ((int)blockIdx.x >= wgs * regions || local >= ngroups) return -1;
+    if (reverse) local = ngroups - 1 - local;
+    return (local * g.share + (it - grp_it * g.share)) * regions + (int)blockIdx.x % regions;
 }
 
 // gather side: terms T0 .. T0 + NT - 1 of every block of the team, as one software pipeline that
@@ -1318,18 +1437,21 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
         QCD_GH_SPIN_DECL;
         float* rcol = &sh.rbuf[member][lane];
         __builtin_amdgcn_s_setprio(QCD_PRIO_ALU);
+        RlxRegs r;   // the generator state: in registers from one site of a stream to the next (share > 1 needs PER = 1)
 #pragma unroll 1
         for (int it = j;; it += PER) {
             const int wb = gh_block<TEAMS>(g, a.nblocks, team, it, a.reverse);
             if (wb < 0) break;
             const SiteRef cur = site_ref<64>(g, wb, lane, parity);
             const __amdgpu_buffer_rsrc_t r_own = link_rsrc<3>(a.U, g, DIR, parity);
-            RlxFast<64, NSKIP> rs;
+            RlxFast<64, NSKIP, true> rs;
             rs.attach(a.rv, cur.stream, rcol);
-            RlxRegs r;
             raw_link own = issue_link<(((nt_mask(DIR) >> 18) & 1u) ? AUX_NT : 0)>(r_own, g, cur.hb);
-            rs.fetch(r);
-            rs.generate(r);
+            const int sub = it % g.share;
+            const bool last = sub == g.share - 1;
+            if (sub == 0) rs.fetch(r);
+            if (last) rs.generate(r);
+            else rs.generate_keep(r);
             const int s = it % GH_SLOTS;
             su3 A = zero<3>();
 #pragma unroll
@@ -1353,7 +1475,16 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
             pin(own);
             su3 Ul = as_su3(own);
             update_link<false>(Ul, A, (real)a.beta_eff, (real)a.beta_inv, a.nhit, rs, fm);
-            used += (unsigned long long)rs.close();
+            if (last) {
+                used += (unsigned long long)rs.close();
+                // the stream is done with this launch: nothing of r goes on to the next block, which fetches
+#pragma unroll
+                for (int k = 0; k < 24; k++) asm volatile("" : "=v"(r.s[k]));
+                asm volatile("" : "=v"(r.c));
+            } else {
+                used += (unsigned long long)rs.pos;
+                rs.carry_over(r);
+            }
             if (a.edge_local > 0 && wb / (g.nzr * g.ntr) < a.edge_local) {
                 store_link_buf<STORE_AUX_THROUGH>(r_own, g, cur.hb, Ul);
                 edge_block_done(a, lane);
@@ -2271,14 +2402,15 @@ __global__ __launch_bounds__(BLOCK) void k_init_hot(real2* __restrict__ U, const
 {
     __shared__ float rbuf[24 * BLOCK];
     constexpr int PER_LINK = (GROUP == 3) ? 12 : 4;
-    const int t = blockIdx.x * BLOCK + threadIdx.x;   // stream = owned half-site index
+    const int t = blockIdx.x * BLOCK + threadIdx.x;   // stream of the owned slab
     unsigned long long used = 0;
-    if (t < g.vh_int) {
-        Site s0 = site_of(g, t, 0);                    // the pair's site of parity 0 ...
-        Site s1 = s0;
-        s1.y ^= 1;                                     // ... and its partner in y, of parity 1
-        const int h = half_index(g, s0);
-        const bool even_first = (s0.y & 1) == 0;       // site 2h is the one with even y
+    if (t < g.vh_int / g.share) {
+        // the stream's site pairs: (xs, yh, z, tp + k tq), k = 0 .. share-1 (stream_of)
+        int q = t;
+        const int yh = q % g.nyh; q /= g.nyh;
+        const int z = q % g.nz; q /= g.nz;
+        const int tp = q % g.tq;
+        const int xs = q / g.tq;
         RlxHome home;
         home.bind(rv, t);
         const int cur = rv.cur;
@@ -2286,15 +2418,22 @@ __global__ __launch_bounds__(BLOCK) void k_init_hot(real2* __restrict__ U, const
         home.load_state(r, cur);
         float* col = rbuf + threadIdx.x;
 #pragma unroll 1
-        for (int dir = 0; dir < 4; dir++) {
-            rlx_batch(r, col, BLOCK);
-            rlx_skip(r, home.q, home.rem);
-            const mat<GROUP> a = hot_link(col, BLOCK, (mat<GROUP>*)nullptr);                     // site 2h
-            const mat<GROUP> b = hot_link(col + PER_LINK * BLOCK, BLOCK, (mat<GROUP>*)nullptr);  // site 2h+1
-            store_link(U, g, dir, 0, h, even_first ? a : b);
-            store_link(U, g, dir, 1, h, even_first ? b : a);
-            used += 2 * PER_LINK;
-        }
+        for (int dir = 0; dir < 4; dir++)
+#pragma unroll 1
+            for (int k = 0; k < g.share; k++) {
+                Site s0;                                   // the pair's site of parity 0
+                s0.xs = xs; s0.z = z; s0.t = tp + k * g.tq;
+                s0.y = 2 * yh + ((g.x0 + xs + z + s0.t) & 1);
+                const int h = half_index(g, s0);
+                const bool even_first = (s0.y & 1) == 0;   // site 2h is the one with even y
+                rlx_batch(r, col, BLOCK);
+                rlx_skip(r, home.q, home.rem);
+                const mat<GROUP> a = hot_link(col, BLOCK, (mat<GROUP>*)nullptr);                     // site 2h
+                const mat<GROUP> b = hot_link(col + PER_LINK * BLOCK, BLOCK, (mat<GROUP>*)nullptr);  // site 2h+1
+                store_link(U, g, dir, 0, h, even_first ? a : b);
+                store_link(U, g, dir, 1, h, even_first ? b : a);
+                used += 2 * PER_LINK;
+            }
         home.store_state(r, cur);   // in front of the stream's next batch, in the same slot: no pass has used it
     }
     used = block_sum_u64<BLOCK>(used);

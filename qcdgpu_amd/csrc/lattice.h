@@ -52,6 +52,11 @@ struct Geom {
     // such a direction a site's neighbour has the SAME parity; only the kernels that look a neighbour's parity
     // up per site (load_site_link) serve such a lattice, and a checkerboard pass runs in phases (update_phase)
     int odd;             // bit 4: twisted boundary condition (general kernels too, no phases of its own)
+    // Random streams: `share` sites of one parity share a stream -- the sites (x, y-pair, z, t' + k tq), k = 0 .. share-1,
+    // tq = nt / share, in this order.  A lane that updates them one after the other moves the generator state once
+    // instead of `share` times.  Partners lie tq apart, not side by side, so that the blocks in flight at one time
+    // still form a compact box of the (z, t) plane.  The regions above then cut the (z, t mod tq) plane: rt = tq / ntr.
+    int share, tq;
     // twist (bit 4 of odd): U_y read at global x = Nx - 1 has its first row times (tw[0] + i tw[1]) and, SU(3), its second
     // row times (tw[2] + i tw[3]); the last row follows from the rows before it as for every stored link
     double tw[4];
@@ -89,17 +94,28 @@ __device__ __forceinline__ Site site_of(const Geom& g, int t, int par)
     s.y = 2 * yh + yb;
     return s;
 }
-// site of parity `par` handled by thread `tid` of workgroup `b` in an update pass; false if
-// the thread has no site.  *stream is the site pair's half index inside the owned slab
-// (the reference's thread index, SU(N)/suncpp/coord_work/coord_work.cpp:151-175).
+// number of the random stream that serves the owned half-site (xs, t, z, yh), inside the owned slab, and the
+// site's place in the stream's order of use (Geom::share)
+__host__ __device__ __forceinline__ int stream_of(const Geom& g, int xs, int t, int z, int yh, int* sub = nullptr)
+{
+    const int k = t / g.tq;
+    if (sub) *sub = k;
+    return ((xs * g.tq + (t - k * g.tq)) * g.nz + z) * g.nyh + yh;
+}
+// site of parity `par` handled by thread `tid` of block `b` in an update pass; false if the thread has no
+// site.  Block b belongs to region b % regions; T = b / regions counts the region's blocks: group T / share
+// (a run of BLOCK half-sites of the region's (z, t mod tq) box, x slowest), member T % share of the group
+// (which of the `share` partner sites).  *stream is the random stream of the site (stream_of); with share = 1
+// it is the site pair's half index inside the owned slab, the reference's thread index
+// (SU(N)/suncpp/coord_work/coord_work.cpp:151-175).
 template <int BLOCK>
 __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid, int par, Site& s, int& stream)
 {
     const int regions = g.nzr * g.ntr;
     const int k = b % regions;
-    int zl, tl, yh;
+    int zl, tl, yh, sub = 0;
     if (g.tz > 0) {
-        // compact block: tiles run z fastest, then t, then x inside the region
+        // compact block (share = 1 only): tiles run z fastest, then t, then x inside the region
         int T = b / regions;
         const int ntz = g.rz / g.tz, ntt = g.rt / g.tt;
         const int Tz = T % ntz;
@@ -114,7 +130,10 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
         tl = Tt * g.tt + r % g.tt;
         s.xs = Tx * g.tx + r / g.tt;
     } else {
-        const int w = (b / regions) * BLOCK + tid;
+        const int T = b / regions;
+        const int grp = T / g.share;
+        sub = T - grp * g.share;
+        const int w = grp * BLOCK + tid;
         if (w >= g.unx * g.region_h) return false;
         s.xs = w / g.region_h;
         int q = w - s.xs * g.region_h;
@@ -127,10 +146,11 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
     s.xs += g.ux0;   // position inside the launch's slice range -> owned slice, wrapping
     if (s.xs >= g.nx) s.xs -= g.nx;
     s.z = (k % g.nzr) * g.rz + zl;
-    s.t = (k / g.nzr) * g.rt + tl;
+    const int tp = (k / g.nzr) * g.rt + tl;   // t mod tq
+    s.t = tp + sub * g.tq;
     const int yb = (par + g.x0 + s.xs + s.z + s.t) & 1;
     s.y = 2 * yh + yb;
-    stream = ((s.xs * g.nt + s.t) * g.nz + s.z) * g.nyh + yh;
+    stream = ((s.xs * g.tq + tp) * g.nz + s.z) * g.nyh + yh;
     return true;
 }
 

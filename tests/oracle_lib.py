@@ -27,6 +27,8 @@ def _load():
     lib.qo_create.argtypes = [I, pi, D, I, I, I, I, U]
     lib.qo_set_twist.argtypes = [P, D, D]
     lib.qo_set_twist.restype = None
+    lib.qo_set_rng_share.argtypes = [P, C.c_int]
+    lib.qo_set_rng_share.restype = C.c_int
     lib.qo_destroy.argtypes = [P]
     lib.qo_init_links.argtypes = [P]
     lib.qo_sweep.argtypes = [P]
@@ -88,10 +90,13 @@ def _L(L):
 class Lattice:
     """One oracle lattice (links AoS [gid*nd+dir], full matrices)."""
 
-    def __init__(self, group, L, beta, nhit=10, ints=1, rng_mode=RNG_SEQ, lux=3, seed=54, phi=0.0, omega=0.0):
+    def __init__(self, group, L, beta, nhit=10, ints=1, rng_mode=RNG_SEQ, lux=3, seed=54, phi=0.0, omega=0.0, share=1):
         self.group, self.L = group, tuple(L)
         self.sites = int(np.prod(L))
         self.h = lib.qo_create(group, _L(L), beta, nhit, ints, rng_mode, lux, seed)
+        if share != 1:   # sites of one parity per stream in the per-thread-stream mode (qcd_params.rng_share)
+            if lib.qo_set_rng_share(self.h, share):
+                raise ValueError("share = %d does not divide Nt = %d" % (share, L[3]))
         lib.qo_init_links(self.h)
         if phi or omega:
             lib.qo_set_twist(self.h, phi, omega)   # twisted boundary condition (PHI, OMEGA)
@@ -196,6 +201,12 @@ def estimates(data):
 def golden(name):
     with open(os.path.join(GOLDEN_DIR, name)) as f:
         return json.load(f)
+
+
+def golden_persite32(share):
+    """The checker's per-thread-stream run of SU(3) 32^4 (oracle/make_golden_persite32.py) with `share` sites of one
+    parity per stream (qcd_params.rng_share; the engine chooses 4 at this size)."""
+    return golden("persite_su3_32x32x32x32_b6%s.json" % ("_share%d" % share if share > 1 else ""))
 
 
 def golden_cases(prefix="ref_"):

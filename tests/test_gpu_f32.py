@@ -202,8 +202,8 @@ def test_su3_32_pair_kernel_path():
     """32^4 SU(3): large launches run as gather / heat-bath wavefront pairs.  Two sweeps from a cold start stay
     within float rounding of the fp64 checker's run of the same lattice (committed fixture; at beta 6 the
     accept/reject decisions of two sweeps are far from their thresholds for all but a handful of links)."""
-    fx = ol.golden("persite_su3_32x32x32x32_b6.json")
     with _ctx(group=3, L=(32, 32, 32, 32), beta=6.0, nhit=10, rand_series=54, precision=1) as c:
+        fx = ol.golden_persite32(c.rng_share)
         c.init_lattice()
         for row in fx["sweeps"]:
             c.sweep(1)

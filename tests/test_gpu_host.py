@@ -424,9 +424,9 @@ def test_32x4_lattice_one_context_equals_eight_slabs():
     numbers after two sweeps, and both equal the CPU checker's fixture for this lattice."""
     import qcdgpu_amd as q
     from qcdgpu_amd import biglattice as bl
-    fx = ol.golden("persite_su3_32x32x32x32_b6.json")
     L = (32, 32, 32, 32)
     with q.Context(group=3, L=L, beta=6.0, nhit=10, rand_series=54) as c:
+        fx = ol.golden_persite32(c.rng_share)
         c.init_lattice()
         c.sweep(2)
         one_p, one_l, one_d = c.plaquette_sums(), c.polyakov_sums(), c.rng_draws()
@@ -499,9 +499,9 @@ def test_ring_one_launch_pass_32_against_checker_fixture(transport):
     the periodic 32^4 lattice (plaquette 1e-12, equal count of random numbers)."""
     import json
     import qcdgpu_amd as q
-    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "persite_su3_32x32x32x32_b6.json")))
     L = (32, 32, 32, 32)
     c = q.Context(group=3, L=L, beta=6.0, nhit=10, rand_series=54, x0=0, nx_local=32, halo=1)
+    fx = ol.golden_persite32(c.rng_share)
     c.init_lattice()
     ring = q.Ring([c], q.RING_COPY if transport == "copy" else q.RING_RCCL)
     try:

@@ -138,14 +138,91 @@ def test_ranlux_runs_match_checker(group, L, beta, nhit, lux, seed):
     lat.close()
 
 
-@pytest.mark.parametrize("group,L,beta", [(3, (8, 6, 4, 8), 5.8), (2, (6, 8, 6, 4), 2.4)])
-def test_hot_start_matches_checker(group, L, beta):
+@pytest.mark.parametrize("group,L,beta,nhit,lux,seed,share", [
+    (3, (8, 8, 8, 8), 6.0, 10, 3, 54, 2),
+    (3, (4, 6, 8, 12), 5.5, 3, 0, 1234, 4),
+    (3, (4, 4, 4, 8), 1.0, 12, 3, 5, 4),     # low beta: most links run past the window, the state goes on from the slow form
+    (3, (6, 4, 4, 6), 1.5, 2, 4, 99, 2),     # many second batches
+    (2, (8, 8, 8, 8), 2.5, 10, 3, 54, 4),
+    (2, (4, 4, 6, 4), 0.5, 14, 1, 8, 2),
+    (3, (5, 4, 3, 6), 5.5, 10, 3, 54, 2),    # odd Nx and Nz: the general kernels, passes in phases
+    (2, (6, 2, 2, 4), 2.3, 5, 2, 11, 4),     # a launch of partly filled blocks
+])
+def test_shared_streams_match_checker(group, L, beta, nhit, lux, seed, share):
+    """rng_share sites of one parity on one RANLUX stream (the sites Nt / rng_share apart in t, updated one after the
+    other by one lane, the generator state passed on in registers or LDS): the checker's per-thread-stream mode
+    with the same map must see the same draw counts and plaquettes; the state left in memory must be the one a
+    fresh context continues from."""
+    import qcdgpu_amd as q
+    lat = ol.Lattice(group, L, beta, nhit=nhit, ints=1, rng_mode=ol.RNG_PERSITE, lux=lux, seed=seed, share=share)
+    with _ctx(group=group, L=L, beta=beta, nhit=nhit, lux_level=lux, rand_series=seed, rng_share=share) as c:
+        assert c.rng_share == share
+        c.init_lattice()
+        for sweep in range(3):
+            c.sweep(1)
+            lat.sweep(1)
+            assert c.rng_draws() == ol.rng_draws(lat), sweep
+            # (rounding differences between the two libms grow fastest in the disordered phase)
+            assert _rel(c.plaquette(), lat.plaquette()) < (REL if beta > 2.0 else 1e-11), sweep
+        got, want = c.download(), lat.export_table()
+        assert np.max(np.abs(got - want)) < (1e-10 if beta > 1.0 else 1e-9)
+        # state round trip: a second context continues bit for bit
+        with q.Context(group=group, L=L, beta=beta, nhit=nhit, lux_level=lux, rand_series=seed + 1, rng_share=share) as b:
+            b.upload(got)
+            b.set_rng_state(c.rng_state())
+            c.sweep(1)
+            b.sweep(1)
+            assert np.array_equal(c.download(), b.download())
+    lat.close()
+    with pytest.raises(q.QcdError):
+        _ctx(group=group, L=(4, 4, 4, 6), beta=beta, rng_share=4)     # must divide Nt
+    with pytest.raises(q.QcdError):
+        _ctx(group=group, L=L, beta=beta, rng_share=3)
+
+
+@pytest.mark.parametrize("share", [2, 4])
+def test_shared_streams_in_the_pair_kernel_and_in_slabs(share, monkeypatch):
+    """The same through the gather / heat-bath pair kernel (forced for a 16^4 lattice) and for the lattice cut into
+    slabs: the stream map is a function of global coordinates."""
+    import qcdgpu_amd as q
+    L = (16, 16, 16, 16)
+    lat = ol.Lattice(3, L, 5.7, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE, share=share)
+    monkeypatch.setenv("QCDGPU_AMD_GH", "2")
+    with _ctx(group=3, L=L, beta=5.7, nhit=10, rng_share=share) as c:
+        monkeypatch.delenv("QCDGPU_AMD_GH")
+        c.init_lattice()
+        parts, x0 = [], 0
+        for nx in (6, 10):
+            parts.append(q.Context(group=3, L=L, beta=5.7, nhit=10, rng_share=share, x0=x0, nx_local=nx, halo=1))
+            parts[-1].init_lattice()
+            x0 += nx
+        ring = q.Ring(parts, q.RING_COPY)
+        try:
+            for sweep in range(2):
+                c.sweep(1)
+                lat.sweep(1)
+                ring.sweep(1)
+                assert c.rng_draws() == ol.rng_draws(lat) == sum(p.rng_draws() for p in parts), sweep
+                assert _rel(c.plaquette(), lat.plaquette()) < REL, sweep
+                sums = np.sum([p.plaquette_sums() for p in parts], axis=0)
+                v = float(np.prod(L))
+                got = np.array([sums[0] / (3 * v), sums[1] / (3 * v), (sums[0] + sums[1]) / (6 * v)])
+                assert _rel(got, lat.plaquette()) < REL, sweep
+        finally:
+            ring.close()
+            for p in parts:
+                p.close()
+    lat.close()
+
+
+@pytest.mark.parametrize("group,L,beta,share", [(3, (8, 6, 4, 8), 5.8, 1), (2, (6, 8, 6, 4), 2.4, 1), (3, (4, 6, 4, 8), 5.8, 4), (2, (6, 4, 6, 4), 2.4, 2)])
+def test_hot_start_matches_checker(group, L, beta, share):
     """Hot start (the reference has it on the device path only: parity unpinned).  The checker
     restates lattice_random3 / lattice_random2 with the same per-thread streams; sin/cos come
     from different libms, so links agree to rounding, not bit for bit."""
     import qcdgpu_amd as q
-    lat = ol.Lattice(group, L, beta, nhit=10, ints=0, rng_mode=ol.RNG_PERSITE, seed=11)
-    with _ctx(group=group, L=L, beta=beta, nhit=10, start_mode=q.START_HOT, rand_series=11) as c:
+    lat = ol.Lattice(group, L, beta, nhit=10, ints=0, rng_mode=ol.RNG_PERSITE, seed=11, share=share)
+    with _ctx(group=group, L=L, beta=beta, nhit=10, start_mode=q.START_HOT, rand_series=11, rng_share=share) as c:
         c.init_lattice()
         assert c.rng_draws() == ol.rng_draws(lat)
         got, want = c.download(), lat.export_table()
@@ -555,14 +632,17 @@ def test_config2_su3_16_heatbath_and_overrelaxation_vs_cpu():
     lat.close()
 
 
-def test_config3_su3_32_against_checker_fixture():
+@pytest.mark.parametrize("share", [0, 1, 2])
+def test_config3_su3_32_against_checker_fixture(share):
     """The benchmark's headline lattice at its stated size: SU(3) 32^4, beta 6, cold start, two heat-bath
     sweeps against the CPU checker's per-thread-stream run of the same lattice (committed fixture,
     oracle/make_golden_persite32.py): plaquette to 1e-12, equal counts of random numbers drawn
-    (the same accept/reject history at every one of 8.4 million link updates), Polyakov loop."""
-    fx = ol.golden("persite_su3_32x32x32x32_b6.json")
+    (the same accept/reject history at every one of 8.4 million link updates), Polyakov loop.
+    share = 0: the library's own choice of sites per stream at this size (4); 1 and 2: asked for."""
     L = (32, 32, 32, 32)
-    with _ctx(group=3, L=L, beta=6.0, nhit=10, rand_series=54) as c:
+    with _ctx(group=3, L=L, beta=6.0, nhit=10, rand_series=54, rng_share=share) as c:
+        assert c.rng_share == (share or 4)
+        fx = ol.golden_persite32(c.rng_share)
         c.init_lattice()
         for row in fx["sweeps"]:
             c.sweep(1)
