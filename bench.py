@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--beta", type=float, default=6.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--brackets", type=int, default=5, help="timed brackets of --steps sweeps each (median reported)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="at N > 1: weak = an L^4 lattice per GPU (lattice (N L) x L^3, the default); strong = ONE L^4 lattice cut "
+                         "into N slabs of L/N slices (the reference's N1 = {L/N, ...}, SU(N)/init_2.dat:10)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
@@ -207,9 +210,17 @@ def main():
 
     p2p_group = None
     n = args.L
-    L = (n * world, n, n, n)
-    sites_per_gpu = n ** 4
+    strong = args.scaling == "strong" and world > 1
+    if strong and n % world:
+        sys.exit("--scaling strong: %d GPUs do not divide L = %d" % (world, n))
+    L = (n, n, n, n) if strong else (n * world, n, n, n)
+    sites_per_gpu = n ** 4 // world if strong else n ** 4
     kw = dict(nhit=10, start_mode=q.START_COLD, lux_level=3, rand_series=54)
+    if strong:
+        # Sites per RANLUX stream (qcd_params.rng_share).  The library chooses it from the full lattice, assuming one
+        # device holds it all; a thin slab has too few groups of sites to keep a device busy with shared streams, so
+        # the cut decides here.  Every rank passes the same value (the stream map is a function of global coordinates).
+        kw["rng_share"] = 2 if world == 2 else 1
 
     if world == 1:
         ctx = q.Context(group=3, L=L, beta=args.beta, device=local_rank, **kw)
@@ -257,9 +268,18 @@ def main():
         sync()
         torch.cuda.synchronize()
 
+    def global_draws():
+        d = int(ctx.rng_draws())
+        if dist is None:
+            return d
+        t = torch.tensor([d], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
     # the first two sweeps from the cold start are compared with the CPU checker's numbers for the
-    # same lattice, seed and stream layout (a committed fixture; they are part of the warm-up)
-    fixture = checker_fixture(L, args.beta, ctx.rng_share) if world == 1 else None
+    # same lattice, seed and stream layout (a committed fixture; they are part of the warm-up).  A cut
+    # lattice is compared like an uncut one: results do not depend on the cut.
+    fixture = checker_fixture(L, args.beta, ctx.rng_share)
     parity_check = None
     done = 0
     if fixture is not None and args.warmup >= 2:
@@ -269,11 +289,33 @@ def main():
             done += 1
             got = plaquette()
             worst = max(worst, max(abs(g - w) / abs(w) for g, w in zip(got, row["plaquette"])))
-            draws_equal = draws_equal and int(ctx.rng_draws()) == int(row["rng_draws"])
+            draws_equal = draws_equal and global_draws() == int(row["rng_draws"])
         parity_check = {"against": "CPU checker, per-thread streams, %s" % fixture["name"],
                         "sweeps": len(fixture["sweeps"]), "max_rel_diff_plaquette": worst,
                         "rng_draws_equal": draws_equal, "ok": bool(worst < 1e-12 and draws_equal)}
         log("parity at 32^4 after %d sweeps: max rel diff %.2e, draws equal %s" % (done, worst, draws_equal))
+    elif world > 1 and transport == "ring" and args.warmup >= 2 and not os.environ.get("QCDGPU_BENCH_NO_CROSSCHECK"):
+        # No CPU fixture at this size: the same slabs driven by the second implementation of the exchange (the Python
+        # driver, halos staged through the host over the process group that is there anyway) must give the same
+        # plaquette and draw count after the first two sweeps; a ring that comes up and moves wrong halos shows here.
+        other = bl.make_rank_slab(3, L, args.beta, rank, world, local_rank, dist_group=None, **kw)
+        worst, draws_equal = 0.0, True
+        for _ in range(2):
+            sweep(1)
+            other.sweep(1)
+            done += 1
+            got, want = plaquette(), other.plaquette()
+            worst = max(worst, max(abs(g - w) / abs(w) for g, w in zip(got, want)))
+            mine, theirs = global_draws(), None
+            t = torch.tensor([int(other.engines[0].ctx.rng_draws())], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            theirs = int(t.item())
+            draws_equal = draws_equal and mine == theirs
+        other.engines[0].ctx.close()
+        parity_check = {"against": "the same slabs with the halos exchanged by the Python driver over torch.distributed (host-staged)",
+                        "sweeps": 2, "max_rel_diff_plaquette": worst, "rng_draws_equal": draws_equal,
+                        "ok": bool(worst < 1e-12 and draws_equal)}
+        log("cross-check of the ring against the second exchange after 2 sweeps: max rel diff %.2e, draws equal %s" % (worst, draws_equal))
     log("warm-up: %d sweeps of %dx%dx%dx%d SU(3) fp64 on %d GPU(s)" % ((args.warmup,) + L + (world,)))
     sweep(max(args.warmup - done, 0))
     barrier()
@@ -309,6 +351,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    if parity_check is not None and not parity_check["ok"]:
+        log("PARITY CHECK FAILED: %s" % json.dumps(parity_check))   # stays in the line as mean_plaquette.parity_check.ok = false
     link_updates = 4.0 * sites_per_gpu * world * args.steps
     value = link_updates / dt
     # dominant kernel: k_update, V/2 link updates per launch; average launch duration from the
@@ -317,6 +361,10 @@ def main():
     # (a slab updates a pass in two launches, boundary slices first: count passes, not launches)
     passes = 8 * args.steps
     assert launches >= passes, (launches, passes)
+    # which kernel a pass over this context's slices runs as (the pair kernel needs enough blocks of sites)
+    kernel_name = "k_update_gh" if ctx.pass_uses_pair_kernel() else "k_update"
+    if world > 1 and launches > passes:
+        kernel_name += " (boundary slices and interior as two launches)"
     per_launch_s = (ev_ms * 1e-3) / passes
     bytes_per_launch = BYTES_PER_LINK_UPDATE_SU3_F64 * sites_per_gpu / 2
     achieved = bytes_per_launch / per_launch_s / 1e9
@@ -329,12 +377,13 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (cold start, beta=%.2f Markov chain, RANLUX3 per-thread streams, seed 54)" % args.beta,
-        "config": {"workload": "SU(3) %dx%dx%dx%d heat-bath sweep (NHIT=10, re-unitarised), %d^4 per GPU"
-                               % (L + (n,)), "lattice": list(L), "beta": args.beta, "nhit": 10,
+        "config": {"workload": ("SU(3) %dx%dx%dx%d heat-bath sweep (NHIT=10, re-unitarised), " % L)
+                               + ("one lattice cut into %d slabs of %d slices" % (world, n // world) if strong else "%d^4 per GPU" % n),
+                   "lattice": list(L), "beta": args.beta, "nhit": 10,
                    "prng": "RANLUX3", "rng_share": ctx.rng_share, "parallelism": "x-slabs x%d" % world,
                    "halo_transport": None if world == 1 else ("RCCL send/recv issued by the C library (qcd_ring)" if transport == "ring"
                                                               else "torch.distributed P2P, backend %s" % backend)},
@@ -347,7 +396,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS,
                      # PMC traffic was collected on this workload (32^4 SU(3) per GPU) only
                      "traffic": measured_traffic() if (n == 32 and args.beta == 6.0) else None,
-                     "kernel": "k_update_gh" if (world == 1 and n >= 16) else "k_update_gh / k_update", "launches": int(launches),
+                     "kernel": kernel_name, "launches": int(launches),
                      "avg_launch_us": 1e6 * per_launch_s,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }

@@ -115,6 +115,12 @@ int qcd_init_lattice(qcd_ctx *ctx);
  * the sites of one parity (0 even, 1 odd), re-unitarisation included */
 int qcd_update(qcd_ctx *ctx, int parity, int dir);
 
+/* Which of the library's two heat-bath kernels a pass over xs_count owned slices runs as: *pair_kernel = 1 for the
+ * gather / heat-bath wavefront-pair kernel (SU(3), per-thread streams, at least two rounds of its teams), 0 for the
+ * kernel with one wavefront per block of sites.  No counterpart in the reference (one kernel per pass there,
+ * suncl.cpp:5359-5374); for programs that label measurements by kernel. */
+int qcd_update_kernel(qcd_ctx *ctx, int xs_count, int *pair_kernel);
+
 /* n full sweeps in the reference order: odd X,Y,Z,T then even X,Y,Z,T (suncpp.h:133-141).
  * Only valid for halo = 0 (a slab needs the halo exchange between passes). */
 int qcd_sweep(qcd_ctx *ctx, int n);
@@ -254,9 +260,12 @@ int    qcd_halo_copy(qcd_ctx *src, int pack_side, qcd_ctx *dst, int recv_side, i
 /* The BIGLAT branch of model::lattice_simulate (suncl.cpp:5026-5138): per (parity, direction) a
  * kernel_run(sun_update_*) for every part followed by model::UpdateEdges(dir) (suncl.cpp:4005-4061).
  * A ring holds the parts (contexts with halo = 1, in ring order) and issues such a pass in ONE call
- * without a host synchronisation: every part updates the slices next to its two faces first
- * (one launch), then the rest of its slab (a second launch behind it on the same stream); the
- * boundary slices are packed, sent, received and unpacked on a stream beside the second launch.
+ * without a host synchronisation.  A part whose pass runs as the wavefront-pair kernel updates its whole slab in
+ * ONE launch that starts with the slices next to its two faces and writes a word of signal memory when those
+ * are in memory (qcd_update_signal_edges); a stream beside the context's waits for that word and moves the
+ * messages while the launch goes on with the interior.  Other parts (SU(2), gid mode, small or ragged slabs,
+ * devices without hipStreamWaitValue32) take two launches on the context's stream, boundary slices first, and
+ * the messages travel beside the second.
  *   QCD_RING_COPY: all parts in this process; messages by device-to-device / peer copies
  *                  (several parts may share a device: the reference's devParts, QCDGPU.cpp:129-134);
  *   QCD_RING_RCCL: ncclSend / ncclRecv between ring neighbours (xGMI between the GPUs of a node);
@@ -266,8 +275,10 @@ int    qcd_halo_copy(qcd_ctx *src, int pack_side, qcd_ctx *dst, int recv_side, i
  * rank 0 makes an identifier with qcd_rccl_unique_id (128 bytes) and hands it to the others by its
  * own means (the reference has no multi-process mode: no counterpart).
  * qcd_ring_update / _overrelax: one pass + exchange; qcd_ring_sweep: n sweeps in the reference's
- * order; qcd_ring_fill_halos: every halo from its owner without an update (once after a hot
- * start; copy transport).  Measurements stay per context (the *_sums entry points). */
+ * order; qcd_ring_fill_halos: every halo from its owner without an update, over the ring's transport (once
+ * after a hot start or an upload: the reference's UpdateEdges x 4 behind its start kernels,
+ * suncl.cpp:4835-4903).  Measurements stay per context (the *_sums entry points).
+ * Destroy a ring BEFORE the contexts it was made of. */
 enum { QCD_RING_COPY = 0, QCD_RING_RCCL = 1 };
 typedef struct qcd_ring qcd_ring;
 int  qcd_ring_create(qcd_ring **out, qcd_ctx *const *parts, int nparts, int transport);

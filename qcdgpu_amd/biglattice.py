@@ -411,10 +411,11 @@ class RingLattice:
 def make_rank_ring(group, L, beta, rank: int, world: int, device_index: int, dist_group=None, **ctx_kw) -> RingLattice:
     """This rank's slab of an L lattice cut evenly over `world` ranks, driven through qcd_ring (RCCL)."""
     from . import capi
-    if ctx_kw.get("start_mode") == capi.START_HOT:
-        raise ValueError("hot start over the RCCL ring: not implemented (start cold or gid)")
     parts = split_even(L[0], world)
     ctx = capi.Context(group=group, L=L, beta=beta, device=device_index, x0=sum(parts[:rank]),
                        nx_local=parts[rank], halo=1, **ctx_kw)
     ctx.init_lattice()
-    return RingLattice(ctx, rank, world, group, L, beta, dist_group)
+    lat = RingLattice(ctx, rank, world, group, L, beta, dist_group)
+    if ctx_kw.get("start_mode") == capi.START_HOT:
+        lat.ring.fill_halos()   # a hot start writes the owned slices only (SU(N)/suncl/suncl.cpp:4835-4903)
+    return lat

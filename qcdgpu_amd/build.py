@@ -53,7 +53,7 @@ def build_host(force=False, verbose=False):
 # another namespace, so that both libraries can be loaded into one process and tell their kernels apart
 # in a profile.
 LIB_F32 = os.path.join(HERE, "lib", "libqcdgpu_amd_f32.so")
-F32_FLAGS = ["-DQCD_REAL=float", "-Dqcd=qcd_f32"]
+F32_FLAGS = ["-DQCD_REAL=float", "-DQCD_NS=qcd_f32"]
 HOST_BIN_F32 = os.path.join(HERE, "bin", "qcdgpu_f32")
 
 

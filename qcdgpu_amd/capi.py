@@ -57,7 +57,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_precision", "qcd_
            "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
-           "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params",
+           "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params", "qcd_update_kernel",
            "qcd_ring_create", "qcd_rccl_unique_id", "qcd_ring_create_rank", "qcd_ring_destroy", "qcd_ring_update",
            "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize", "qcd_ring_one_launch_passes"]
 
@@ -95,6 +95,7 @@ def _load(path=None):
     lib.qcd_measure_plaquette_sums_static.argtypes = [P, P]
     lib.qcd_get_stream.argtypes = [P, C.POINTER(P)]
     lib.qcd_get_params.argtypes = [P, C.POINTER(Params)]
+    lib.qcd_update_kernel.argtypes = [P, I, C.POINTER(I)]
     lib.qcd_ring_create.argtypes = [C.POINTER(P), C.POINTER(P), I, I]
     lib.qcd_rccl_unique_id.argtypes = [P, C.c_size_t]
     lib.qcd_ring_create_rank.argtypes = [C.POINTER(P), P, I, I, P, C.c_size_t]
@@ -207,6 +208,12 @@ class Context:
         p = Params()
         self._check(self.lib.qcd_get_params(self.h, C.byref(p)))
         return p.rng_share
+
+    def pass_uses_pair_kernel(self, xs_count=None):
+        """Whether a heat-bath pass over xs_count owned slices (default: all) runs as k_update_gh."""
+        v = C.c_int(0)
+        self._check(self.lib.qcd_update_kernel(self.h, self.params.nx_local if xs_count is None else xs_count, C.byref(v)))
+        return bool(v.value)
 
     def close(self):
         if getattr(self, "h", None):

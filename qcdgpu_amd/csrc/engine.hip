@@ -19,7 +19,7 @@
 #include "host_seed.h"
 #include "kernels.h"
 
-using namespace qcd;
+using namespace QCD_NS;
 
 namespace {
 
@@ -82,13 +82,13 @@ int static_scratch_setup(int device)
 }  // namespace
 
 // error text of the other translation units of the library (qcd_last_error returns it)
-namespace qcd {
+namespace QCD_NS {
 int fail_msg(int code, const char* msg)
 {
     g_err = msg;
     return code;
 }
-}  // namespace qcd
+}  // namespace QCD_NS
 
 struct qcd_ctx {
     qcd_params p;
@@ -168,6 +168,20 @@ struct Timed {
     }
 };
 
+// whether a heat-bath pass over xs_count owned slices runs as the gather / heat-bath pair kernel (k_update_gh): SU(3),
+// per-thread streams, even extents, whole blocks of sites and enough of them for the kernel's teams
+bool pass_is_paired(const qcd_ctx* c, int xs_count)
+{
+    const Geom& g = c->g;
+    if (c->p.group != 3 || c->p.start_mode == QCD_START_GID || UPD_BLOCK != 64 || g.odd || g.tz != 0 || c->gh_grid <= 0) return false;
+    if (((long)xs_count * g.region_h) % UPD_BLOCK != 0) return false;   // the kernel has no code for partly filled blocks
+    // shared streams need the kernel's teams to be pairs of wavefronts: a heat-bath wavefront then takes every block of its team
+    if (g.share > 1 && GH_TEAMS != GH_SIDE) return false;
+    const int ngroups = g.nzr * g.ntr * (int)cdiv((long)xs_count * g.region_h, UPD_BLOCK);
+    const int nblocks = ngroups * g.share;
+    return c->gh_mode == 2 || (c->gh_mode == 1 && nblocks >= 2 * GH_SIDE * c->gh_grid && ngroups >= GH_SIDE * c->gh_grid);
+}
+
 // NSKIP: 223 = RANLUX3 (the reference's default, QCDGPU.cpp:98) with the skip unrolled at compile
 // time; 0 = any luxury level, skip count at run time
 template <int GROUP, bool GID, int NSKIP>
@@ -238,11 +252,7 @@ int launch_update_dir(qcd_ctx* c, int parity, int dir, int xs_begin, int xs_coun
         return QCD_OK;
     }
     if constexpr (GROUP == 3 && !GID && UPD_BLOCK == 64) {
-        // it has no code for partly filled blocks
-        const bool full = ((long)g.unx * g.region_h) % UPD_BLOCK == 0 && g.tz == 0;
-        // (shared streams need the kernel's teams to be pairs of wavefronts: a heat-bath wavefront then takes every block of its team)
-        if (c->gh_grid > 0 && full && (g.share == 1 || GH_TEAMS == GH_SIDE) &&
-            (c->gh_mode == 2 || (c->gh_mode == 1 && nblocks >= 2 * GH_SIDE * c->gh_grid && ngroups >= GH_SIDE * c->gh_grid))) {
+        if (pass_is_paired(c, xs_count)) {
             paired = true;
             if (edge_slices > 0) {
                 // the launch starts at the last `edge_slices` slices and wraps to the first ones: with
@@ -831,6 +841,15 @@ int qcd_init_lattice(qcd_ctx* c)
     // the caller may switch streams right after this call: leave nothing in flight
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->initialized = true;
+    return QCD_OK;
+}
+
+int qcd_update_kernel(qcd_ctx* c, int xs_count, int* pair_kernel)
+{
+    int rc = check_ctx(c, false, false, true);
+    if (rc) return rc;
+    if (!pair_kernel || xs_count < 1 || xs_count > c->g.nx) return fail(QCD_ERR_INVALID, "qcd_update_kernel: %d slices of %d", xs_count, c->g.nx);
+    *pair_kernel = pass_is_paired(c, xs_count) ? 1 : 0;
     return QCD_OK;
 }
 
@@ -1695,10 +1714,10 @@ int qcd_host_rlx_pack_check(unsigned seed, int n, unsigned* errors)
 // diagnostic build only: sleeps the two sides of the gather / heat-bath pairs spent waiting for each other
 extern "C" int qcd_debug_gh_spins(unsigned long long out[2], int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(qcd::g_gh_spins), 16);
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(QCD_NS::g_gh_spins), 16);
     if (e == hipSuccess && reset) {
         unsigned long long z[2] = {0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(qcd::g_gh_spins), z, 16);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(QCD_NS::g_gh_spins), z, 16);
     }
     return (int)e;
 }
@@ -1708,6 +1727,6 @@ extern "C" int qcd_debug_gh_spins(unsigned long long out[2], int reset)
 // diagnostic build only: copies the per-wave phase stamps of the last k_update launch
 extern "C" int qcd_debug_read_trace(void* dst, size_t bytes)
 {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(qcd::g_trace), bytes);
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(QCD_NS::g_trace), bytes);
 }
 #endif

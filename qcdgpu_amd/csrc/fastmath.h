@@ -22,7 +22,12 @@
 #define QCD_REAL double
 #endif
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 using real = QCD_REAL;
 constexpr bool REAL_IS_DOUBLE = sizeof(real) == 8;
@@ -184,4 +189,4 @@ struct MathFast {
     }
 };
 
-}  // namespace qcd
+}  // namespace QCD_NS

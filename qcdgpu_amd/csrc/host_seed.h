@@ -13,7 +13,12 @@
 
 #include "ranlux.h"
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 class GlibcRand {
 public:
@@ -80,4 +85,4 @@ inline std::vector<int> stream_seeds(unsigned rand_series, long first, long coun
     return out;
 }
 
-}  // namespace qcd
+}  // namespace QCD_NS

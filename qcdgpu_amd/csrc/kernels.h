@@ -18,7 +18,12 @@
 #include "ranlux.h"
 #include "su_math.h"
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 // delivered RANLUX batches held in LDS per thread by the update kernel
 constexpr int RLX_WINDOW = 2;
@@ -2556,4 +2561,4 @@ __global__ __launch_bounds__(BLOCK) void k_halo(real2* __restrict__ U, const Geo
     else *p = buf[i];
 }
 
-}  // namespace qcd
+}  // namespace QCD_NS

@@ -21,7 +21,12 @@
 
 #include "su_math.h"
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 struct Geom {
     int nx, ny, nz, nt;  // owned (interior) extents; nx = number of owned x slices
@@ -384,4 +389,4 @@ __device__ __forceinline__ int off_bwd(const NbrOff& n, int dir)
     return dir == 0 ? n.b0 : (dir == 1 ? n.b1 : (dir == 2 ? n.b2 : n.b3));
 }
 
-}  // namespace qcd
+}  // namespace QCD_NS

@@ -18,9 +18,9 @@
 #include "host_seed.h"
 #include "on_kernels.h"
 
-using namespace qcd;
+using namespace QCD_NS;
 
-namespace qcd {
+namespace QCD_NS {
 int fail_msg(int code, const char* msg);
 }
 

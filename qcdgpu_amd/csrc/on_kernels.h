@@ -21,7 +21,12 @@
 #include "kernels.h"
 #include "ranlux.h"
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 struct OnGeom {
     int nx, ny, nz, nt;
@@ -480,4 +485,4 @@ __global__ __launch_bounds__(BLOCK) void k_on_convert(F* __restrict__ phi, const
     else table[gid] = phi[(size_t)par * g.vh + h];
 }
 
-}  // namespace qcd
+}  // namespace QCD_NS

@@ -18,7 +18,12 @@
 
 #include <hip/hip_runtime.h>
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 constexpr int RLX_STATE_WORDS = 25;  // 24 words + carry
 constexpr float RLX_TWOM24 = 0.000000059604644775390625f;
@@ -170,4 +175,4 @@ __host__ __device__ __forceinline__ void rlx_batch(RlxRegs& r, OutT* out, int st
     }
 }
 
-}  // namespace qcd
+}  // namespace QCD_NS

@@ -41,7 +41,12 @@
 #include <string>
 #include <vector>
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 int fail_msg(int code, const char* msg);
 }
 
@@ -51,7 +56,7 @@ int failf(int code, const char* fmt, const char* a = "", const char* b = "")
 {
     char buf[512];
     snprintf(buf, sizeof(buf), fmt, a, b);
-    return qcd::fail_msg(code, buf);
+    return QCD_NS::fail_msg(code, buf);
 }
 
 #define RING_HIP(expr)                                                                  \
@@ -156,26 +161,36 @@ int region_of(const Part& p, int side, int owned, int dir, int parity, Region& g
 // Up to two messages moved by one launch (blockIdx.y picks the message): the runs of a slice to
 // or from a contiguous buffer, or straight from a boundary slice into a halo slice on the same device.
 struct CopyJob {
-    const double2* src;
-    double2* dst;
-    size_t src_pitch, dst_pitch;   // in elements
+    const char* src;
+    char* dst;
+    size_t src_pitch, dst_pitch;   // in bytes
 };
 struct CopyJobs {
     CopyJob job[2];
 };
+// T: the unit a lane moves -- 16 bytes where runs and pitches allow it, else 8 (a stored complex number of the
+// single-precision library is 8 bytes, so a run of an odd number of them is no whole number of 16-byte units)
+template <class T>
 __global__ __launch_bounds__(256) void k_slice_copy(const CopyJobs jobs, const int per_piece, const int pieces)
 {
     const CopyJob j = jobs.job[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= per_piece * pieces) return;
     const int c = i / per_piece, r = i - c * per_piece;
-    j.dst[(size_t)c * j.dst_pitch + r] = j.src[(size_t)c * j.src_pitch + r];
+    ((T*)(j.dst + (size_t)c * j.dst_pitch))[r] = ((const T*)(j.src + (size_t)c * j.src_pitch))[r];
 }
 
 int launch_slice_copy(const CopyJobs& jobs, int njobs, const Region& shape, hipStream_t stream)
 {
-    const int per = (int)(shape.bytes / sizeof(double2)), n = per * shape.pieces;
-    hipLaunchKernelGGL(k_slice_copy, dim3((n + 255) / 256, njobs), dim3(256), 0, stream, jobs, per, shape.pieces);
+    bool wide = shape.bytes % 16 == 0;
+    for (int k = 0; k < njobs; k++)
+        wide = wide && jobs.job[k].src_pitch % 16 == 0 && jobs.job[k].dst_pitch % 16 == 0 &&
+               ((size_t)jobs.job[k].src | (size_t)jobs.job[k].dst) % 16 == 0;
+    if (shape.bytes % 8 != 0) return failf(QCD_ERR_UNSUPPORTED, "the runs of a slice are not a multiple of 8 bytes long");
+    const int unit = wide ? 16 : 8;
+    const int per = (int)(shape.bytes / unit), n = per * shape.pieces;
+    if (wide) hipLaunchKernelGGL(k_slice_copy<double2>, dim3((n + 255) / 256, njobs), dim3(256), 0, stream, jobs, per, shape.pieces);
+    else hipLaunchKernelGGL(k_slice_copy<double>, dim3((n + 255) / 256, njobs), dim3(256), 0, stream, jobs, per, shape.pieces);
     RING_HIP(hipGetLastError());
     return QCD_OK;
 }
@@ -312,11 +327,10 @@ int part_update(qcd_ring* r, Part& p, int parity, int dir, bool heatbath)
 }
 
 // copy transport: the halos of `me` from the boundary slices of its neighbours, on me's lane
-int pull(qcd_ring* r, Part& me, Part& left, Part& right, int dir, int parity)
+int pull(qcd_ring* r, Part& me, Part& left, Part& right, int dir, int parity, int njobs)
 {
-    // left halo <- left neighbour's last slice; right halo <- right neighbour's first slice (not
-    // for X links: nothing reads U_x one slice to the right)
-    const int njobs = dir != 0 ? 2 : 1;
+    // left halo <- left neighbour's last slice; right halo <- right neighbour's first slice (njobs = 1: the left
+    // halo only)
     Part* from[2] = {&left, &right};
     Region src[2], dst[2];
     int rc;
@@ -330,7 +344,7 @@ int pull(qcd_ring* r, Part& me, Part& left, Part& right, int dir, int parity)
     int same = 0;
     for (int s = 0; s < njobs; s++) {
         if (from[s]->device == me.device) {
-            jobs.job[same++] = CopyJob{(const double2*)src[s].first, (double2*)dst[s].first, src[s].pitch / sizeof(double2), dst[s].pitch / sizeof(double2)};
+            jobs.job[same++] = CopyJob{src[s].first, dst[s].first, src[s].pitch, dst[s].pitch};
         } else {
             for (int c = 0; c < src[s].pieces; c++)
                 RING_HIP(hipMemcpyPeerAsync(dst[s].first + c * dst[s].pitch, me.device, src[s].first + c * src[s].pitch, from[s]->device, src[s].bytes,
@@ -341,15 +355,28 @@ int pull(qcd_ring* r, Part& me, Part& left, Part& right, int dir, int parity)
     return QCD_OK;
 }
 
+int exchange(qcd_ring* r, int parity, int dir, int sides);
+
 int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
 {
     if (!r) return failf(QCD_ERR_INVALID, "null ring");
     if (parity != 0 && parity != 1) return failf(QCD_ERR_INVALID, "parity must be 0 or 1");
     if (dir < 0 || dir > 3) return failf(QCD_ERR_INVALID, "direction must be 0..3");
-    const int n = (int)r->parts.size();
     int rc;
     for (Part& p : r->parts)
         if ((rc = part_update(r, p, parity, dir, heatbath))) return rc;
+    // after a pass over U_dir the right halo is stale for dir != X only: nothing reads U_x one slice to the right
+    if ((rc = exchange(r, parity, dir, dir != 0 ? 2 : 1))) return rc;
+    r->passes++;
+    return QCD_OK;
+}
+
+// The boundary slices of U_dir on the sites of one parity to the neighbours' halos, for every part; each part's
+// `ready` event (lane) says from when on its boundary slices may be read.  sides = 2: both halos; 1: the left one only.
+int exchange(qcd_ring* r, int parity, int dir, int sides)
+{
+    const int n = (int)r->parts.size();
+    int rc;
     // The messages go from lattice to lattice: a boundary slice of the links (dir, parity) is a few
     // contiguous runs (one per stored matrix element), and so is the halo slice it goes to.  The
     // pass itself never reads U_dir on sites of this parity, so a halo may be overwritten while the
@@ -360,12 +387,12 @@ int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
         for (int k = 0; k < n; k++) {
             Part& me = r->parts[k];
             RING_HIP(hipSetDevice(me.device));
-            if ((rc = pull(r, me, r->parts[(k + n - 1) % n], r->parts[(k + 1) % n], dir, parity))) return rc;
+            if ((rc = pull(r, me, r->parts[(k + n - 1) % n], r->parts[(k + 1) % n], dir, parity, sides))) return rc;
             RING_HIP(hipEventRecord(me.halo_done, me.lane));
         }
     } else {
         Rccl* nc = rccl();
-        const int njobs = dir != 0 ? 2 : 1;
+        const int njobs = sides;
         const size_t count = r->bytes / sizeof(double);
         for (Part& p : r->parts) {
             // gather the runs of the last slice (to the right neighbour) and of the first (to the left)
@@ -374,7 +401,7 @@ int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
             CopyJobs jobs = {};
             for (int s = 0; s < njobs; s++) {
                 if ((rc = region_of(p, 1 - s, 1, dir, parity, reg[s]))) return rc;
-                jobs.job[s] = CopyJob{(const double2*)reg[s].first, (double2*)p.out[1 - s], reg[s].pitch / sizeof(double2), reg[s].bytes / sizeof(double2)};
+                jobs.job[s] = CopyJob{reg[s].first, p.out[1 - s], reg[s].pitch, reg[s].bytes};
             }
             if ((rc = launch_slice_copy(jobs, njobs, reg[0], p.lane))) return rc;
         }
@@ -385,7 +412,7 @@ int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
             const int right = (me + 1) % r->world, left = (me + r->world - 1) % r->world;
             RING_NCCL(nc->Send(p.out[1], count, ncclDouble, right, p.comm, p.lane));
             RING_NCCL(nc->Recv(p.in[0], count, ncclDouble, left, p.comm, p.lane));
-            if (dir != 0) {
+            if (sides == 2) {
                 RING_NCCL(nc->Send(p.out[0], count, ncclDouble, left, p.comm, p.lane));
                 RING_NCCL(nc->Recv(p.in[1], count, ncclDouble, right, p.comm, p.lane));
             }
@@ -398,7 +425,7 @@ int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
             CopyJobs jobs = {};
             for (int s = 0; s < njobs; s++) {
                 if ((rc = region_of(p, s, 0, dir, parity, reg[s]))) return rc;
-                jobs.job[s] = CopyJob{(const double2*)p.in[s], (double2*)reg[s].first, reg[s].bytes / sizeof(double2), reg[s].pitch / sizeof(double2)};
+                jobs.job[s] = CopyJob{p.in[s], reg[s].first, reg[s].bytes, reg[s].pitch};
             }
             if ((rc = launch_slice_copy(jobs, njobs, reg[0], p.lane))) return rc;
             RING_HIP(hipEventRecord(p.halo_done, p.lane));
@@ -410,7 +437,6 @@ int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
         RING_HIP(hipSetDevice(p.device));
         RING_HIP(hipStreamWaitEvent(p.stream, p.halo_done, 0));
     }
-    r->passes++;
     return QCD_OK;
 }
 
@@ -499,7 +525,8 @@ void qcd_ring_destroy(qcd_ring* r)
     if (!r) return;
     for (Part& p : r->parts) {
         (void)hipSetDevice(p.device);
-        if (p.stream) (void)hipStreamSynchronize(p.stream);
+        // the lane orders everything the ring issued; the context's stream belongs to the context, which may be gone
+        // already if the caller destroyed it first (it should not: see the header)
         if (p.lane) (void)hipStreamSynchronize(p.lane);
         if (p.comm && rccl()->lib) (void)rccl()->CommDestroy(p.comm);
         if (p.edge_done) (void)hipEventDestroy(p.edge_done);
@@ -534,20 +561,22 @@ int qcd_ring_sweep(qcd_ring* r, int n)
 int qcd_ring_fill_halos(qcd_ring* r)
 {
     if (!r) return failf(QCD_ERR_INVALID, "null ring");
-    // every halo slice from its owner, without an update (needed once after a hot start)
+    // Every halo slice from its owner, without an update: needed once after a hot start or an upload (the reference:
+    // UpdateEdges for all four directions after the start kernels, SU(N)/suncl/suncl.cpp:4835-4903).  The same
+    // exchange as behind a pass, over either transport, for all directions, both parities and both halos.
+    int rc;
+    for (Part& p : r->parts) {
+        void* st = nullptr;
+        if ((rc = qcd_get_stream(p.ctx, &st))) return rc;
+        p.stream = (hipStream_t)st;
+        RING_HIP(hipSetDevice(p.device));
+        RING_HIP(hipEventRecord(p.edge_done, p.stream));    // whatever wrote the links is in this stream
+        RING_HIP(hipStreamWaitEvent(p.lane, p.edge_done, 0));
+        RING_HIP(hipEventRecord(p.ready, p.lane));
+    }
     for (int dir = 0; dir < 4; dir++)
-        for (int parity = 0; parity < 2; parity++) {
-            const int n = (int)r->parts.size();
-            if (r->transport == QCD_RING_COPY) {
-                for (int k = 0; k < n; k++) {
-                    int rc = qcd_halo_copy(r->parts[k].ctx, 1, r->parts[(k + 1) % n].ctx, 0, dir, parity);
-                    if (rc) return rc;
-                    if ((rc = qcd_halo_copy(r->parts[(k + 1) % n].ctx, 0, r->parts[k].ctx, 1, dir, parity))) return rc;
-                }
-            } else {
-                return failf(QCD_ERR_UNSUPPORTED, "halo fill over RCCL: start cold or gid, or fill with the copy transport");
-            }
-        }
+        for (int parity = 0; parity < 2; parity++)
+            if ((rc = exchange(r, parity, dir, 2))) return rc;
     return QCD_OK;
 }
 

@@ -11,7 +11,12 @@
 
 #include "fastmath.h"
 
-namespace qcd {
+// the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
+// libraries can be loaded into one process and a profile tells their kernels apart
+#ifndef QCD_NS
+#define QCD_NS qcd
+#endif
+namespace QCD_NS {
 
 struct cplx {
     real re, im;
@@ -211,4 +216,4 @@ __device__ __forceinline__ void gram_schmidt(su2& a)
     reconstruct(a);
 }
 
-}  // namespace qcd
+}  // namespace QCD_NS

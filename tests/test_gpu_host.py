@@ -585,6 +585,42 @@ def test_ring_over_rccl_on_one_gpu(by_rank):
         lat.close()
 
 
+@pytest.mark.parametrize("transport,group", [("rccl", 3), ("rank", 3), ("copy", 2), ("rccl", 2)])
+def test_hot_start_fills_halos_over_the_ring_transport(transport, group):
+    """Hot start of a slab: the start kernel writes the owned slices, the halos come from the neighbours through
+    qcd_ring_fill_halos -- the reference's UpdateEdges x 4 behind its start kernels (SU(N)/suncl/suncl.cpp:4835-4903) --
+    over the ring's own transport, RCCL included (a world of one sends to itself).  Halos poisoned first; then the
+    hot lattice and two sweeps against the checker's hot start of the periodic lattice."""
+    import qcdgpu_amd as q
+    L = (8, 4, 6, 4)
+    beta = 5.7 if group == 3 else 2.4
+    lat = ol.Lattice(group, L, beta, nhit=5, ints=0, rng_mode=ol.RNG_PERSITE, seed=23)
+    c = q.Context(group=group, L=L, beta=beta, nhit=5, rand_series=23, x0=0, nx_local=L[0], halo=1, start_mode=q.START_HOT)
+    c.init_lattice()
+    if transport == "rank":
+        ring = q.Ring([c], rank=0, world=1, unique_id=q.Ring.unique_id())
+    else:
+        ring = q.Ring([c], q.RING_RCCL if transport == "rccl" else q.RING_COPY)
+    try:
+        ring.fill_halos()
+        assert np.max(np.abs(c.download() - lat.export_table())) < 1e-14
+        sums = c.plaquette_sums()      # reads the right halo
+        v = float(np.prod(L))
+        got = np.array([sums[0] / (3 * v), sums[1] / (3 * v), (sums[0] + sums[1]) / (6 * v)])
+        assert np.max(np.abs(got - lat.plaquette())) < 1e-13
+        for s in range(2):
+            ring.sweep(1)
+            lat.sweep(1)
+            sums = c.plaquette_sums()
+            got = np.array([sums[0] / (3 * v), sums[1] / (3 * v), (sums[0] + sums[1]) / (6 * v)])
+            assert np.max(np.abs(got - lat.plaquette()) / np.abs(lat.plaquette())) < 1e-11
+        assert c.rng_draws() == ol.rng_draws(lat)
+    finally:
+        ring.close()
+        c.close()
+        lat.close()
+
+
 def test_cli_state_file_with_fmunu_sections(tmp_path):
     """The state file with F0MU = 1 and no plaquette average: the reference writes its
     lattice_energies_plq section whenever plaquettes OR either field tensor is measured

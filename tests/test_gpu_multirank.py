@@ -41,7 +41,7 @@ def _run(world, cfg, tmp_path):
 
 @pytest.mark.parametrize("world,cfg", [
     (2, dict(group=3, L=[16, 4, 4, 6], beta=5.8, nhit=4, seed=29, ints=1, sweeps=2)),
-    (2, dict(group=3, L=[16, 4, 4, 6], beta=1.0, nhit=12, seed=29, ints=1, sweeps=2)),   # redo lists of both lanes busy
+    (2, dict(group=3, L=[16, 4, 4, 6], beta=1.0, nhit=12, seed=29, ints=1, sweeps=2)),   # low beta: most links run past their window of random numbers
     (4, dict(group=2, L=[16, 4, 6, 4], beta=2.3, nhit=5, seed=7, ints=1, sweeps=2)),     # Nx = 4 per rank
     (2, dict(group=3, L=[8, 4, 4, 4], beta=5.9, nhit=4, seed=3, ints=0, sweeps=1)),      # hot start: halos by exchange
 ])
@@ -94,6 +94,25 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert doc["value"] > 0 and doc["roofline"]["launches"] >= 16
     # 5 sweeps of 32 x 16^3 from a cold start at beta = 6: the plaquette has left 3 and is still above its equilibrium value
     assert 1.7 < doc["mean_plaquette"]["Plq_total"] < 2.2
+
+
+def test_bench_strong_scaling_cuts_one_lattice(tmp_path):
+    """`bench.py --gpus 2 --scaling strong`: ONE 32^4 lattice cut into two slabs of 16 slices (the reference's
+    N1 = {16, 16}), both ranks on the box's one device.  The line says "strong", counts the link updates of one
+    lattice, and its first two sweeps equal the CPU checker's fixture for the uncut 32^4 lattice."""
+    env = dict(os.environ, QCDGPU_BENCH_SHARE_DEVICE="1", QCDGPU_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
+                        "--brackets", "1", "--L", "32", "--scaling", "strong", "--no-cpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    doc = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert doc["scaling"] == "strong" and doc["n_gpus"] == 2 and doc["config"]["lattice"] == [32, 32, 32, 32]
+    assert doc["config"]["rng_share"] == 2
+    assert doc["mean_plaquette"]["parity_check"]["ok"], doc["mean_plaquette"]["parity_check"]
+    assert "share2" in doc["mean_plaquette"]["parity_check"]["against"]
+    assert abs(doc["value"] * doc["ms_per_step"] * 1e-3 - 4 * 32 ** 4) < 1.0      # one lattice's link updates per sweep
+    assert doc["roofline"]["algorithmic_bytes_per_launch"] == 864 * 32 ** 4 / 4   # half the lattice per GPU, half its sites per pass
 
 
 def test_bench_falls_back_when_the_rccl_ring_does_not_come_up(tmp_path):
