@@ -220,7 +220,7 @@ def main():
         # Sites per RANLUX stream (qcd_params.rng_share).  The library chooses it from the full lattice, assuming one
         # device holds it all; a thin slab has too few groups of sites to keep a device busy with shared streams, so
         # the cut decides here.  Every rank passes the same value (the stream map is a function of global coordinates).
-        kw["rng_share"] = 2 if world == 2 else 1
+        kw["rng_share"] = q.rng_share_for(L, n // world)
 
     if world == 1:
         ctx = q.Context(group=3, L=L, beta=args.beta, device=local_rank, **kw)

@@ -115,6 +115,11 @@ int qcd_init_lattice(qcd_ctx *ctx);
  * the sites of one parity (0 even, 1 odd), re-unitarisation included */
 int qcd_update(qcd_ctx *ctx, int parity, int dir);
 
+/* The value rng_share = 0 stands for: sites per RANLUX stream for a lattice L cut into parts of at least
+ * min_nx_local x-slices (min_nx_local = L[0]: uncut, what qcd_create itself assumes).  A host that cuts the lattice
+ * passes the result to every part, so that thin parts are not left with too few streams to fill a device. */
+int qcd_rng_share_for(const int L[4], int min_nx_local);
+
 /* Which of the library's two heat-bath kernels a pass over xs_count owned slices runs as: *pair_kernel = 1 for the
  * gather / heat-bath wavefront-pair kernel (SU(3), per-thread streams, at least two rounds of its teams), 0 for the
  * kernel with one wavefront per block of sites.  No counterpart in the reference (one kernel per pass there,

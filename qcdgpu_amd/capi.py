@@ -57,7 +57,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_precision", "qcd_
            "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
-           "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params", "qcd_update_kernel",
+           "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params", "qcd_update_kernel", "qcd_rng_share_for",
            "qcd_ring_create", "qcd_rccl_unique_id", "qcd_ring_create_rank", "qcd_ring_destroy", "qcd_ring_update",
            "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize", "qcd_ring_one_launch_passes"]
 
@@ -96,6 +96,7 @@ def _load(path=None):
     lib.qcd_get_stream.argtypes = [P, C.POINTER(P)]
     lib.qcd_get_params.argtypes = [P, C.POINTER(Params)]
     lib.qcd_update_kernel.argtypes = [P, I, C.POINTER(I)]
+    lib.qcd_rng_share_for.argtypes = [C.POINTER(I), I]
     lib.qcd_ring_create.argtypes = [C.POINTER(P), C.POINTER(P), I, I]
     lib.qcd_rccl_unique_id.argtypes = [P, C.c_size_t]
     lib.qcd_ring_create_rank.argtypes = [C.POINTER(P), P, I, I, P, C.c_size_t]
@@ -172,6 +173,11 @@ def lib_f32():
 def _check(rc, l=None):
     if rc != 0:
         raise QcdError(rc, (l or lib).qcd_last_error().decode())
+
+
+def rng_share_for(L, min_nx_local=None):
+    """Sites per RANLUX stream the library would choose for lattice L cut into parts of at least min_nx_local slices."""
+    return lib.qcd_rng_share_for((C.c_int * 4)(*L), L[0] if min_nx_local is None else min_nx_local)
 
 
 class Context:

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "host_seed.h"
@@ -72,7 +73,11 @@ double2* g_scratch_ptr[STATIC_MAX_DEVICES];   // device address of `scratch` on 
 // so that the entry point itself finds the address ready.
 int static_scratch_setup(int device)
 {
-    if (device < 0 || device >= STATIC_MAX_DEVICES || g_scratch_ptr[device]) return QCD_OK;
+    // (a device beyond the table is served by every entry point but the one that needs the workspace, which says so)
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return QCD_OK;
+    static std::mutex mu;   // contexts may be created from several host threads
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_scratch_ptr[device]) return QCD_OK;
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     g_scratch_ptr[device] = (double2*)p;
@@ -609,12 +614,7 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     // lattices whose pass keeps the device busy even then: at least 2048 groups of 64 sites per pass.
     g.share = p->rng_share;
     if (g.share == 0) {
-        const long blocks = sites / 2 / 64;
-        g.share = 1;
-        if (!g.odd) {
-            if (p->L[3] % 4 == 0 && blocks / 4 >= 2048) g.share = 4;
-            else if (p->L[3] % 2 == 0 && blocks / 2 >= 2048) g.share = 2;
-        }
+        g.share = (g.odd & 16) ? 1 : qcd_rng_share_for(p->L, p->L[0]);
         if (const char* ov = getenv("QCDGPU_AMD_SHARE")) {   // diagnostic override of the automatic choice
             const int v = atoi(ov);
             if ((v == 1 || v == 2 || v == 4) && p->L[3] % v == 0) g.share = v;
@@ -844,6 +844,17 @@ int qcd_init_lattice(qcd_ctx* c)
     return QCD_OK;
 }
 
+int qcd_rng_share_for(const int L[4], int min_nx_local)
+{
+    if (!L || min_nx_local < 1 || ((L[0] | L[2] | L[3]) & 1)) return 1;
+    // sharing divides the number of independent units of work of a pass, so it is for parts whose pass keeps the
+    // device busy even then: at least 2048 groups of 64 sites per pass and part
+    const long blocks = (long)min_nx_local * (L[1] / 2) * L[2] * L[3] / 64;
+    if (L[3] % 4 == 0 && blocks / 4 >= 2048) return 4;
+    if (blocks / 2 >= 2048) return 2;
+    return 1;
+}
+
 int qcd_update_kernel(qcd_ctx* c, int xs_count, int* pair_kernel)
 {
     int rc = check_ctx(c, false, false, true);
@@ -1041,7 +1052,9 @@ int qcd_measure_plaquette_sums_static(qcd_ctx* c, double* sums_dev)
     if (c->npartial > STATIC_PARTIALS_MAX)
         return fail(QCD_ERR_UNSUPPORTED, "%d workgroups of partial sums exceed the static workspace of %d (at most %ld owned sites)",
                     c->npartial, STATIC_PARTIALS_MAX, (long)STATIC_PARTIALS_MAX * MEAS_BLOCK);
-    double2* ws = (c->p.device < STATIC_MAX_DEVICES) ? g_scratch_ptr[c->p.device] : nullptr;
+    if (c->p.device >= STATIC_MAX_DEVICES)
+        return fail(QCD_ERR_UNSUPPORTED, "the static workspace is kept for devices 0..%d; this context runs on device %d", STATIC_MAX_DEVICES - 1, c->p.device);
+    double2* ws = g_scratch_ptr[c->p.device];
     if (!ws) return fail(QCD_ERR_STATE, "no static workspace on device %d", c->p.device);
     int nparts = 0;
     if ((rc = launch_plaquette_into(c, ws, nullptr, &nparts))) return rc;

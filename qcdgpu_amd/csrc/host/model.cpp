@@ -303,6 +303,13 @@ void model::lattice_init(void)
     for (auto& s : SubLat) total += s.Nx;
     if (total != lattice_full_size[0]) throw model_error("N1 = {..} does not add up to L1");
 
+    // sites per random stream: one value for all parts, chosen for the thinnest of them
+    int rng_share = RNGSHARE;
+    if (rng_share == 0) {
+        int min_nx = lattice_full_size[0];
+        for (auto& s : SubLat) min_nx = s.Nx < min_nx ? s.Nx : min_nx;
+        rng_share = (PHI != 0.0 || OMEGA != 0.0) ? 1 : qcd_rng_share_for(lattice_full_size, min_nx);
+    }
     int x0 = 0;
     for (auto& s : SubLat) {
         qcd_params p;
@@ -313,7 +320,7 @@ void model::lattice_init(void)
         p.precision = (int)precision_word();
         p.phi = PHI;
         p.omega = OMEGA;
-        p.rng_share = RNGSHARE;
+        p.rng_share = rng_share;
         p.beta = BETA;
         p.nhit = NHIT;
         p.start_mode = (ints == model_start_hot) ? QCD_START_HOT : (ints == model_start_gid ? QCD_START_GID : QCD_START_COLD);

@@ -36,9 +36,14 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // the C++ names of the library live in namespace QCD_NS: qcd, or qcd_f32 in the single-precision build, so that both
@@ -125,8 +130,16 @@ Rccl* rccl()
         if (e_ != ncclSuccess) return failf(QCD_ERR_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(e_)); \
     } while (0)
 
+// a message where it lies in a lattice: `pieces` runs of `bytes`, `pitch` apart
+struct Region {
+    char* first = nullptr;
+    size_t bytes = 0, pitch = 0;
+    int pieces = 0;
+};
+
 struct Part {
     qcd_ctx* ctx = nullptr;
+    Region region[2][2][4][2];          // [side][owned][direction][parity]: qcd_halo_region
     int device = 0, nx = 0;
     hipStream_t stream = nullptr;       // the context's stream: the update launches
     hipStream_t lane = nullptr;         // beside it: what moves the messages of a pass (copy transport: the copies themselves)
@@ -143,14 +156,12 @@ struct Part {
     unsigned signal_seq = 0;
 };
 
-// a message where it lies in a lattice: `pieces` runs of `bytes`, `pitch` apart
-struct Region {
-    char* first = nullptr;
-    size_t bytes = 0, pitch = 0;
-    int pieces = 0;
-};
-
 int region_of(const Part& p, int side, int owned, int dir, int parity, Region& g)
+{
+    g = p.region[side][owned][dir][parity];   // asked for once, when the ring was made: a context's geometry does not change
+    return QCD_OK;
+}
+int region_ask(const Part& p, int side, int owned, int dir, int parity, Region& g)
 {
     void* f = nullptr;
     const int rc = qcd_halo_region(p.ctx, side, owned, dir, parity, &f, &g.bytes, &g.pitch, &g.pieces);
@@ -197,13 +208,96 @@ int launch_slice_copy(const CopyJobs& jobs, int njobs, const Region& shape, hipS
 
 }  // namespace
 
+// One host thread per part, as the reference runs its parts under USE_OPENMP (one OpenMP thread per device,
+// SU(N)/suncl/suncl.cpp:639-658, 2123-2128, 4018-4024): the handful of HIP calls a pass needs per part (26 us from one
+// thread) are issued side by side, so the host's share of a pass does not grow with the number of parts.
+// A step of a pass is a function of the part's number, run for all parts; the caller waits for all of them.
+// Workers spin for the next step for a while (passes of a sweep follow one another at once), then sleep.
+struct Pool {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable go, done;
+    std::atomic<unsigned long> step{0};     // number of the step posted last
+    std::atomic<int> pending{0};            // parts that have not finished it
+    std::function<int(int)> fn;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+    bool stop = false;
+
+    void worker(int k)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            unsigned long s = step.load(std::memory_order_acquire);
+            for (int spin = 0; s == seen && spin < 20000; spin++) {
+                __builtin_ia32_pause();
+                s = step.load(std::memory_order_acquire);
+            }
+            if (s == seen) {
+                std::unique_lock<std::mutex> lk(m);
+                go.wait(lk, [&] { return stop || step.load(std::memory_order_acquire) != seen; });
+                if (stop) return;
+                s = step.load(std::memory_order_acquire);
+            }
+            {
+                std::lock_guard<std::mutex> lk(m);   // `stop` and `fn` are written under the lock
+                if (stop) return;
+            }
+            seen = s;
+            rc[k] = fn(k);
+            if (rc[k] != QCD_OK) msg[k] = qcd_last_error();   // the message is this thread's: hand it over
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(m);
+                done.notify_one();
+            }
+        }
+    }
+    void start(int n)
+    {
+        rc.assign(n, QCD_OK);
+        msg.assign(n, std::string());
+        for (int k = 0; k < n; k++) threads.emplace_back([this, k] { worker(k); });
+    }
+    // f(k) for every part k, on the parts' threads; the first failure's code (its message becomes the caller's)
+    int run(const std::function<int(int)>& f)
+    {
+        const int n = (int)threads.size();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            fn = f;
+            pending.store(n, std::memory_order_release);
+            step.fetch_add(1, std::memory_order_acq_rel);
+        }
+        go.notify_all();
+        for (int spin = 0; pending.load(std::memory_order_acquire) != 0 && spin < 200000; spin++) __builtin_ia32_pause();
+        if (pending.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return pending.load(std::memory_order_acquire) == 0; });
+        }
+        for (int k = 0; k < n; k++)
+            if (rc[k] != QCD_OK) return QCD_NS::fail_msg(rc[k], msg[k].c_str());
+        return QCD_OK;
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        go.notify_all();
+        for (std::thread& t : threads) t.join();
+        threads.clear();
+    }
+};
+
 struct qcd_ring {
     std::vector<Part> parts;
+    Pool* pool = nullptr;       // null: every step runs on the caller's thread, part after part
     int transport = QCD_RING_COPY;
     int rank0 = 0, world = 1;   // ring position of parts[0] and ring size (world > parts.size(): one part per process)
     size_t bytes = 0;
     unsigned long long passes = 0;
-    unsigned long long signalled = 0;   // part-passes issued as one launch with the edge signal
+    std::atomic<unsigned long long> signalled{0};   // part-passes issued as one launch with the edge signal (counted from the parts' threads)
     int edge_override = 0;
     bool one_launch = true;
 };
@@ -263,6 +357,11 @@ int ring_add_parts(qcd_ring* r, qcd_ctx* const* parts, int nparts)
         p.device = prm.device;
         p.nx = prm.nx_local;
         p.stream = (hipStream_t)st;
+        for (int side = 0; side < 2; side++)
+            for (int owned = 0; owned < 2; owned++)
+                for (int dir = 0; dir < 4; dir++)
+                    for (int parity = 0; parity < 2; parity++)
+                        if ((rc = region_ask(p, side, owned, dir, parity, p.region[side][owned][dir][parity]))) return rc;
         const size_t b = qcd_halo_bytes(parts[k]);
         if (k && b != r->bytes) return failf(QCD_ERR_INVALID, "parts with different slice shapes");
         r->bytes = b;
@@ -355,89 +454,110 @@ int pull(qcd_ring* r, Part& me, Part& left, Part& right, int dir, int parity, in
     return QCD_OK;
 }
 
-int exchange(qcd_ring* r, int parity, int dir, int sides);
+// a step of a pass for every part: on the parts' own threads when the ring has them, else part after part
+int for_parts(qcd_ring* r, const std::function<int(int)>& f)
+{
+    if (r->pool) return r->pool->run(f);
+    for (int k = 0; k < (int)r->parts.size(); k++) {
+        const int rc = f(k);
+        if (rc) return rc;
+    }
+    return QCD_OK;
+}
+
+// The boundary slices of U_dir on the sites of one parity to the neighbours' halos, for every part; each part's
+// `ready` event (lane) says from when on its boundary slices may be read and must be recorded before this is
+// called.  sides = 2: both halos; 1: the left one only.
+// The messages go from lattice to lattice: a boundary slice of the links (dir, parity) is a few
+// contiguous runs (one per stored matrix element), and so is the halo slice it goes to.  The
+// pass itself never reads U_dir on sites of this parity, so a halo may be overwritten while the
+// part's own launch is still running; a boundary slice is not written again before the same
+// (parity, dir) comes round, eight passes later, and no part gets more than two passes ahead
+// of a neighbour.
+int exchange(qcd_ring* r, int parity, int dir, int sides)
+{
+    const int n = (int)r->parts.size();
+    int rc;
+    // whatever comes next on a context's stream -- the next pass, a measurement -- finds the halos current
+    auto finish = [r](Part& p) -> int {
+        RING_HIP(hipEventRecord(p.halo_done, p.lane));
+        RING_HIP(hipStreamWaitEvent(p.stream, p.halo_done, 0));
+        return QCD_OK;
+    };
+    if (r->transport == QCD_RING_COPY)
+        return for_parts(r, [=](int k) -> int {
+            Part& me = r->parts[k];
+            RING_HIP(hipSetDevice(me.device));
+            const int rc2 = pull(r, me, r->parts[(k + n - 1) % n], r->parts[(k + 1) % n], dir, parity, sides);
+            return rc2 ? rc2 : finish(me);
+        });
+    Rccl* nc = rccl();
+    const size_t count = r->bytes / sizeof(double);
+    // gather the runs of the last slice (to the right neighbour) and of the first (to the left)
+    rc = for_parts(r, [=](int k) -> int {
+        Part& p = r->parts[k];
+        RING_HIP(hipSetDevice(p.device));
+        Region reg[2];
+        CopyJobs jobs = {};
+        for (int s = 0; s < sides; s++) {
+            const int rc2 = region_of(p, 1 - s, 1, dir, parity, reg[s]);
+            if (rc2) return rc2;
+            jobs.job[s] = CopyJob{reg[s].first, p.out[1 - s], reg[s].pitch, reg[s].bytes};
+        }
+        return launch_slice_copy(jobs, sides, reg[0], p.lane);
+    });
+    if (rc) return rc;
+    // one group for all parts of this process, from the calling thread
+    RING_NCCL(nc->GroupStart());
+    for (int k = 0; k < n; k++) {
+        Part& p = r->parts[k];
+        const int me = r->rank0 + k;
+        const int right = (me + 1) % r->world, left = (me + r->world - 1) % r->world;
+        RING_NCCL(nc->Send(p.out[1], count, ncclDouble, right, p.comm, p.lane));
+        RING_NCCL(nc->Recv(p.in[0], count, ncclDouble, left, p.comm, p.lane));
+        if (sides == 2) {
+            RING_NCCL(nc->Send(p.out[0], count, ncclDouble, left, p.comm, p.lane));
+            RING_NCCL(nc->Recv(p.in[1], count, ncclDouble, right, p.comm, p.lane));
+        }
+    }
+    RING_NCCL(nc->GroupEnd());
+    return for_parts(r, [=](int k) -> int {
+        Part& p = r->parts[k];
+        RING_HIP(hipSetDevice(p.device));
+        // (the lane gathers the next pass's messages behind this: the outgoing buffers are sent by then)
+        Region reg[2];
+        CopyJobs jobs = {};
+        for (int s = 0; s < sides; s++) {
+            const int rc2 = region_of(p, s, 0, dir, parity, reg[s]);
+            if (rc2) return rc2;
+            jobs.job[s] = CopyJob{p.in[s], reg[s].first, reg[s].bytes, reg[s].pitch};
+        }
+        const int rc2 = launch_slice_copy(jobs, sides, reg[0], p.lane);
+        return rc2 ? rc2 : finish(p);
+    });
+}
 
 int ring_pass(qcd_ring* r, int parity, int dir, bool heatbath)
 {
     if (!r) return failf(QCD_ERR_INVALID, "null ring");
     if (parity != 0 && parity != 1) return failf(QCD_ERR_INVALID, "parity must be 0 or 1");
     if (dir < 0 || dir > 3) return failf(QCD_ERR_INVALID, "direction must be 0..3");
-    int rc;
-    for (Part& p : r->parts)
-        if ((rc = part_update(r, p, parity, dir, heatbath))) return rc;
+    // every part's `ready` event is recorded before any part waits for a neighbour's
+    int rc = for_parts(r, [=](int k) -> int { return part_update(r, r->parts[k], parity, dir, heatbath); });
+    if (rc) return rc;
     // after a pass over U_dir the right halo is stale for dir != X only: nothing reads U_x one slice to the right
     if ((rc = exchange(r, parity, dir, dir != 0 ? 2 : 1))) return rc;
     r->passes++;
     return QCD_OK;
 }
 
-// The boundary slices of U_dir on the sites of one parity to the neighbours' halos, for every part; each part's
-// `ready` event (lane) says from when on its boundary slices may be read.  sides = 2: both halos; 1: the left one only.
-int exchange(qcd_ring* r, int parity, int dir, int sides)
+// one host thread per part when the ring has more than one (QCDGPU_AMD_RING_THREADS = 0: never)
+void ring_start_threads(qcd_ring* r)
 {
-    const int n = (int)r->parts.size();
-    int rc;
-    // The messages go from lattice to lattice: a boundary slice of the links (dir, parity) is a few
-    // contiguous runs (one per stored matrix element), and so is the halo slice it goes to.  The
-    // pass itself never reads U_dir on sites of this parity, so a halo may be overwritten while the
-    // part's own launch is still running; a boundary slice is not written again before the same
-    // (parity, dir) comes round, eight passes later, and no part gets more than two passes ahead
-    // of a neighbour.
-    if (r->transport == QCD_RING_COPY) {
-        for (int k = 0; k < n; k++) {
-            Part& me = r->parts[k];
-            RING_HIP(hipSetDevice(me.device));
-            if ((rc = pull(r, me, r->parts[(k + n - 1) % n], r->parts[(k + 1) % n], dir, parity, sides))) return rc;
-            RING_HIP(hipEventRecord(me.halo_done, me.lane));
-        }
-    } else {
-        Rccl* nc = rccl();
-        const int njobs = sides;
-        const size_t count = r->bytes / sizeof(double);
-        for (Part& p : r->parts) {
-            // gather the runs of the last slice (to the right neighbour) and of the first (to the left)
-            RING_HIP(hipSetDevice(p.device));
-            Region reg[2];
-            CopyJobs jobs = {};
-            for (int s = 0; s < njobs; s++) {
-                if ((rc = region_of(p, 1 - s, 1, dir, parity, reg[s]))) return rc;
-                jobs.job[s] = CopyJob{reg[s].first, p.out[1 - s], reg[s].pitch, reg[s].bytes};
-            }
-            if ((rc = launch_slice_copy(jobs, njobs, reg[0], p.lane))) return rc;
-        }
-        RING_NCCL(nc->GroupStart());
-        for (int k = 0; k < n; k++) {
-            Part& p = r->parts[k];
-            const int me = r->rank0 + k;
-            const int right = (me + 1) % r->world, left = (me + r->world - 1) % r->world;
-            RING_NCCL(nc->Send(p.out[1], count, ncclDouble, right, p.comm, p.lane));
-            RING_NCCL(nc->Recv(p.in[0], count, ncclDouble, left, p.comm, p.lane));
-            if (sides == 2) {
-                RING_NCCL(nc->Send(p.out[0], count, ncclDouble, left, p.comm, p.lane));
-                RING_NCCL(nc->Recv(p.in[1], count, ncclDouble, right, p.comm, p.lane));
-            }
-        }
-        RING_NCCL(nc->GroupEnd());
-        for (Part& p : r->parts) {
-            RING_HIP(hipSetDevice(p.device));
-            // (the lane gathers the next pass's messages behind this: the outgoing buffers are sent by then)
-            Region reg[2];
-            CopyJobs jobs = {};
-            for (int s = 0; s < njobs; s++) {
-                if ((rc = region_of(p, s, 0, dir, parity, reg[s]))) return rc;
-                jobs.job[s] = CopyJob{p.in[s], reg[s].first, reg[s].bytes, reg[s].pitch};
-            }
-            if ((rc = launch_slice_copy(jobs, njobs, reg[0], p.lane))) return rc;
-            RING_HIP(hipEventRecord(p.halo_done, p.lane));
-        }
-    }
-    // whatever comes next on a context's stream -- the next pass, a measurement -- finds the halos
-    // current
-    for (Part& p : r->parts) {
-        RING_HIP(hipSetDevice(p.device));
-        RING_HIP(hipStreamWaitEvent(p.stream, p.halo_done, 0));
-    }
-    return QCD_OK;
+    const char* ov = getenv("QCDGPU_AMD_RING_THREADS");
+    if (r->parts.size() < 2 || (ov && atoi(ov) == 0)) return;
+    r->pool = new Pool();
+    r->pool->start((int)r->parts.size());
 }
 
 }  // namespace
@@ -474,6 +594,7 @@ int qcd_ring_create(qcd_ring** out, qcd_ctx* const* parts, int nparts, int trans
         qcd_ring_destroy(r);
         return rc;
     }
+    ring_start_threads(r);
     *out = r;
     return QCD_OK;
 }
@@ -523,6 +644,11 @@ int qcd_ring_create_rank(qcd_ring** out, qcd_ctx* part, int rank, int world, con
 void qcd_ring_destroy(qcd_ring* r)
 {
     if (!r) return;
+    if (r->pool) {
+        r->pool->shutdown();
+        delete r->pool;
+        r->pool = nullptr;
+    }
     for (Part& p : r->parts) {
         (void)hipSetDevice(p.device);
         // the lane orders everything the ring issued; the context's stream belongs to the context, which may be gone
@@ -564,16 +690,19 @@ int qcd_ring_fill_halos(qcd_ring* r)
     // Every halo slice from its owner, without an update: needed once after a hot start or an upload (the reference:
     // UpdateEdges for all four directions after the start kernels, SU(N)/suncl/suncl.cpp:4835-4903).  The same
     // exchange as behind a pass, over either transport, for all directions, both parities and both halos.
-    int rc;
-    for (Part& p : r->parts) {
+    int rc = for_parts(r, [=](int k) -> int {
+        Part& p = r->parts[k];
         void* st = nullptr;
-        if ((rc = qcd_get_stream(p.ctx, &st))) return rc;
+        const int rc2 = qcd_get_stream(p.ctx, &st);
+        if (rc2) return rc2;
         p.stream = (hipStream_t)st;
         RING_HIP(hipSetDevice(p.device));
         RING_HIP(hipEventRecord(p.edge_done, p.stream));    // whatever wrote the links is in this stream
         RING_HIP(hipStreamWaitEvent(p.lane, p.edge_done, 0));
         RING_HIP(hipEventRecord(p.ready, p.lane));
-    }
+        return QCD_OK;
+    });
+    if (rc) return rc;
     for (int dir = 0; dir < 4; dir++)
         for (int parity = 0; parity < 2; parity++)
             if ((rc = exchange(r, parity, dir, 2))) return rc;
@@ -583,7 +712,7 @@ int qcd_ring_fill_halos(qcd_ring* r)
 int qcd_ring_one_launch_passes(qcd_ring* r, unsigned long long* n)
 {
     if (!r || !n) return failf(QCD_ERR_INVALID, "null argument");
-    *n = r->signalled;
+    *n = r->signalled.load();
     return QCD_OK;
 }
 

@@ -585,6 +585,39 @@ def test_ring_over_rccl_on_one_gpu(by_rank):
         lat.close()
 
 
+@pytest.mark.parametrize("threads", ["1", "0"])
+def test_ring_of_eight_parts_one_host_thread_per_part(threads, monkeypatch):
+    """Eight parts driven by one process, as the reference's BigLattice on an 8-GPU node (one OpenMP thread per device,
+    SU(N)/suncl/suncl.cpp:639-658): the ring issues every step of a pass on one host thread per part (or, switched off,
+    part after part from the caller's thread).  Same links as the uncut lattice of the checker either way."""
+    import qcdgpu_amd as q
+    L = (16, 8, 8, 8)
+    monkeypatch.setenv("QCDGPU_AMD_RING_THREADS", threads)
+    lat = ol.Lattice(3, L, 5.8, nhit=6, ints=1, rng_mode=ol.RNG_PERSITE, seed=41)
+    ctxs = [q.Context(group=3, L=L, beta=5.8, nhit=6, rand_series=41, x0=2 * k, nx_local=2, halo=1) for k in range(8)]
+    for c in ctxs:
+        c.init_lattice()
+    ring = q.Ring(ctxs, q.RING_COPY)
+    try:
+        for s in range(3):
+            ring.sweep(1)
+            lat.sweep(1)
+        for parity in (1, 0):
+            for d in range(4):
+                ring.overrelax(parity, d)
+        lat.overrelax_sweep(1)
+        assert sum(c.rng_draws() for c in ctxs) == ol.rng_draws(lat)
+        got = np.concatenate([c.download() for c in ctxs], axis=1)
+        assert np.max(np.abs(got - lat.export_table())) < 1e-10
+        with pytest.raises(q.QcdError):      # an error on a part's thread comes back as the caller's
+            ring.update(0, 7)
+    finally:
+        ring.close()
+        for c in ctxs:
+            c.close()
+        lat.close()
+
+
 @pytest.mark.parametrize("transport,group", [("rccl", 3), ("rank", 3), ("copy", 2), ("rccl", 2)])
 def test_hot_start_fills_halos_over_the_ring_transport(transport, group):
     """Hot start of a slab: the start kernel writes the owned slices, the halos come from the neighbours through
