@@ -321,6 +321,7 @@ void model::lattice_init(void)
         p.phi = PHI;
         p.omega = OMEGA;
         p.rng_share = rng_share;
+        rng_share_used_ = rng_share;
         p.beta = BETA;
         p.nhit = NHIT;
         p.start_mode = (ints == model_start_hot) ? QCD_START_HOT : (ints == model_start_gid ? QCD_START_GID : QCD_START_COLD);
@@ -618,6 +619,9 @@ std::vector<unsigned int> model::lattice_make_bin_header(void) const   // suncl.
     r[k++] = (unsigned int)lattice_nd;
     for (int i = 0; i < lattice_nd; i++) r[k++] = (unsigned int)lattice_full_size[i];
     for (int i = 0; i < lattice_nd; i++) r[k++] = (unsigned int)lattice_domain_size[i];
+    // the reference leaves the rest of the header zero and does not read it; the last word says how many sites share
+    // a random stream in this engine (the generator states behind the link table are laid out by it)
+    r[BIN_HEADER_SIZE - 1] = (unsigned int)rng_share_used_;
     return r;
 }
 
@@ -666,6 +670,9 @@ bool model::lattice_load_bin_header(const unsigned int* head)   // suncl.cpp:199
     if (lattice_nd != 4) return false;
     for (int i = 0; i < lattice_nd; i++) lattice_full_size[i] = (int)head[k++];
     for (int i = 0; i < lattice_nd; i++) lattice_domain_size[i] = (int)head[k++];
+    // (zero in a file the reference wrote: one stream per site pair, and no generator states to lay out)
+    const unsigned int share = head[BIN_HEADER_SIZE - 1];
+    if (share == 1 || share == 2 || share == 4) RNGSHARE = (int)share;
     return true;
 }
 
@@ -725,13 +732,13 @@ void model::lattice_save_state(void)
     }
     fwrite(table.data(), qb, (size_t)rows * rs, stream);
 
-    // per-thread generator state in global stream order
-    const size_t NS = (size_t)lattice_full_size[0] * gslice / 2;
+    // per-thread generator state in global stream order (rng_share_used_ sites of one parity per stream)
+    const size_t NS = (size_t)lattice_full_size[0] * gslice / 2 / (size_t)rng_share_used_;
     std::vector<unsigned int> ctl(NS), slots(2 * 25 * NS);
     unsigned long long draws = 0;
     size_t first = 0;
     for (auto& s : SubLat) {
-        const size_t ns = (size_t)s.Nx * gslice / 2;
+        const size_t ns = (size_t)s.Nx * gslice / 2 / (size_t)rng_share_used_;
         std::vector<unsigned char> st(qcd_rng_state_bytes(s.ctx));
         check(qcd_rng_state_download(s.ctx, st.data(), st.size()), "qcd_rng_state_download");
         unsigned long long d;
@@ -870,7 +877,7 @@ void model::lattice_load_state(void)
     // generator state (absent in files the reference wrote: the streams then start from their seeds)
     char magic[8];
     unsigned long long ns64 = 0, draws = 0;
-    const size_t NS = (size_t)lattice_full_size[0] * gslice / 2;
+    const size_t NS = (size_t)lattice_full_size[0] * gslice / 2 / (size_t)rng_share_used_;
     if (fread(magic, 1, 8, stream) == 8 && !memcmp(magic, "QCDRLX1", 8) && fread(&ns64, sizeof(ns64), 1, stream) == 1 &&
         fread(&draws, sizeof(draws), 1, stream) == 1 && ns64 == NS) {
         std::vector<unsigned int> ctl(NS), slots(2 * 25 * NS);
@@ -882,7 +889,7 @@ void model::lattice_load_state(void)
         size_t first = 0;
         bool first_part = true;
         for (auto& s : SubLat) {
-            const size_t ns = (size_t)s.Nx * gslice / 2;
+            const size_t ns = (size_t)s.Nx * gslice / 2 / (size_t)rng_share_used_;
             std::vector<unsigned char> st(qcd_rng_state_bytes(s.ctx));
             const unsigned long long d = first_part ? draws : 0ull;   // the total is kept on the first part
             memcpy(st.data(), &d, sizeof(d));

@@ -207,6 +207,7 @@ private:
     void measure(int index);
     void check(int rc, const char* what);
     unsigned int LOAD_state = 0;
+    int rng_share_used_ = 1;   // sites per random stream the contexts were created with (RNGSHARE, or the library's choice)
     std::vector<unsigned int> lattice_make_bin_header(void) const;
     bool lattice_load_bin_header(const unsigned int* head);
     unsigned int energies_size() const;

@@ -1,4 +1,5 @@
 """The C++ host shell (qcdgpu binary: init.dat -> run -> result file) and BigLattice on a GPU."""
+import json
 import math
 import os
 import re
@@ -652,6 +653,119 @@ def test_hot_start_fills_halos_over_the_ring_transport(transport, group):
         ring.close()
         c.close()
         lat.close()
+
+
+QCG_CHECK = os.path.join(ROOT, "oracle", "_ref", "qcdgpu_qcg_check")
+
+
+def read_with_reference_reader(qcg, f0mu=0):
+    """A state file through the reference's own reader and CPU re-measurement (oracle/ref_qcg_driver.cpp:
+    model::lattice_load_state twice, then lattice_check_cpu on the table it loaded): header fields, stored samples,
+    re-measured values."""
+    r = subprocess.run([QCG_CHECK, str(qcg), str(f0mu)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    head, samples, check = {}, [], {}
+    for line in r.stdout.splitlines():
+        w = line.split()
+        if not w:
+            continue
+        if w[0] == "sample":
+            row, i = {}, 2
+            for name, n in (("energies", 2), ("plq", 2), ("wilson", 1), ("polyakov", 2)):
+                if i < len(w) and w[i] == name:
+                    row[name] = [float(x) for x in w[i + 1:i + 1 + n]]
+                    i += 1 + n
+            samples.append(row)
+        elif w[0].startswith("check_"):
+            check[w[0][6:]] = float(w[1])
+        elif w[0] in ("L", "domain"):
+            head[w[0]] = [int(x) for x in w[1:]]
+        elif len(w) == 2:
+            try:
+                head[w[0]] = float(w[1]) if w[0] in ("BETA", "PHI", "OMEGA") else int(w[1])
+            except ValueError:
+                pass
+    return head, samples, check
+
+
+QCG_CASES = {
+    "su3_plain": dict(GROUP=3, ND=4, L1=4, L2=4, L3=4, L4=6, BETA=5.8, NHIT=4, INTS=1, PRNG="RANLUX3", RANDSERIES=41, NAV=1, ITER=5, NITER=1),
+    "su3_fmunu_wilson": dict(GROUP=3, ND=4, L1=4, L2=6, L3=4, L4=4, BETA=5.6, NHIT=5, INTS=1, PRNG="RANLUX2", RANDSERIES=7, NAV=2, ITER=4, NITER=2,
+                             FMUNU=1, FMUNU1=1, FMUNU6=1, GETWILSON=1, WILSONR=2, WILSONT=2, GETRETRACE=1),
+    "su3_f0mu_twist_hot": dict(GROUP=3, ND=4, L1=4, L2=4, L3=6, L4=4, BETA=5.9, NHIT=4, INTS=0, PRNG="RANLUX3", RANDSERIES=19, NAV=1, ITER=4, NITER=1,
+                               F0MU=1, FMUNU2=1, FMUNU6=1, PHI=0.4, OMEGA=-0.3),
+    "su2_plain": dict(GROUP=2, ND=4, L1=6, L2=4, L3=4, L4=4, BETA=2.4, NHIT=6, INTS=1, PRNG="RANLUX3", RANDSERIES=23, NAV=1, ITER=5, NITER=1),
+    "su2_wilson_nopl": dict(GROUP=2, ND=4, L1=4, L2=4, L3=4, L4=8, BETA=2.6, NHIT=6, INTS=2, PRNG="RANLUX1", RANDSERIES=5, NAV=0, ITER=4, NITER=1,
+                            GETWILSON=1, WILSONR=1, WILSONT=3, PL_LEVEL=0, GETRETRACE=1),
+}
+
+
+@pytest.mark.parametrize("case", sorted(QCG_CASES))
+def test_state_file_is_read_by_the_reference_reader(tmp_path, case):
+    """A .qcg file written by `qcdgpu --save-state` through the REFERENCE's reader (model::lattice_load_bin_header and
+    model::lattice_load_state, SU(N)/suncl/suncl.cpp:1990-2079, compiled from the reference's sources by
+    `make -C oracle ref_qcg`): every header field comes back as the init file set it, the sample sections hold the
+    numbers of the result table in the reference's normalisation, and the reference's CPU re-measurement of the link
+    table it loaded (lattice_check_cpu) gives the sample measured on that configuration."""
+    if not os.path.exists(QCG_CHECK):
+        pytest.skip("oracle/_ref/qcdgpu_qcg_check is not built (make -C oracle ref_qcg needs /root/reference)")
+    keys = QCG_CASES[case]
+    _, fields, full, _ = _run(tmp_path / "a", keys)
+    stop = keys["ITER"] - 1
+    _, _, _, out = _run(tmp_path / "b", keys, args=["--save-state", "--save-every", "1e9", "--stop-at", str(stop)])
+    qcg = re.findall(r"state file: (\S+)", out)[-1]
+    head, samples, check = read_with_reference_reader(qcg, keys.get("F0MU", 0))
+    # header
+    L = [keys["L1"], keys["L2"], keys["L3"], keys["L4"]]
+    assert head["L"] == L and head["domain"] == L and head["group"] == keys["GROUP"] and head["nd"] == 4
+    assert head["ints"] == keys["INTS"] and head["randseries"] == keys["RANDSERIES"]
+    lux = int(keys["PRNG"][-1])
+    assert head["nskip"] == [24, 48, 97, 223, 389][lux] and head["generator"] == 2 + lux
+    for k in ("NAV", "NITER", "ITER", "NHIT"):
+        assert head[k] == keys[k], k
+    assert head["BETA"] == keys["BETA"] and head["PHI"] == keys.get("PHI", 0.0) and head["OMEGA"] == keys.get("OMEGA", 0.0)
+    assert head["precision"] == 2 and head["PL_level"] == keys.get("PL_LEVEL", 3)
+    assert head["get_Fmunu"] == (1 if "FMUNU" in keys else 0) and head["get_wilson_loop"] == (1 if "GETWILSON" in keys else 0)
+    if "GETWILSON" in keys:
+        assert (head["wilson_R"], head["wilson_T"]) == (keys["WILSONR"], keys["WILSONT"])
+    if "FMUNU" in keys or "F0MU" in keys:
+        # FMUNU1/2/4 choose the first Gell-Mann index (3 otherwise), FMUNU5/6/7 the second (8 otherwise): suncl.cpp:424-453
+        idx = [int(k[5:]) for k in keys if k.startswith("FMUNU") and k[5:].isdigit()]
+        want_idx = [([i for i in idx if i in (1, 2, 4)] or [3])[-1], ([i for i in idx if i in (5, 6, 7)] or [8])[-1]]
+        assert [head["Fmunu_index1"], head["Fmunu_index2"]] == want_idx
+        assert head["energies_size_F"] == 7 * head["energies_size"]
+    else:
+        assert head["energies_size_F"] == head["energies_size"]
+    assert head["ITER_counter"] == stop == len(samples) and head["NAV_counter"] == keys["NAV"]   # stopped with `stop` samples taken
+    # stored samples against the uninterrupted run's result table (normalisations: SU(N)/suncl/suncl.cpp:1340-1348, 1486-1492)
+    col = {f: i for i, f in enumerate(fields)}
+    v = float(np.prod(L))
+    n3, g = float(L[0] * L[1] * L[2]), float(keys["GROUP"])
+    for i, row in enumerate(samples):
+        assert np.allclose(np.array(row["energies"]) / (3 * v), full[i, [col["S_spat"], col["S_temp"]]], rtol=1e-12, atol=1e-15)
+        if "plq" in row:
+            assert np.allclose(np.array(row["plq"]) / (3 * v), full[i, [col["Plq_spat"], col["Plq_temp"]]], rtol=1e-12)
+        if "wilson" in row:
+            assert abs(row["wilson"][0] / (3 * v) - full[i, col["Wilson_loop"]]) < 1e-12
+        if "polyakov" in row:
+            assert np.allclose(np.array(row["polyakov"]) / (n3 * g), full[i, [col["Polyakov_loop"], col["Polyakov_loop_im"]]], rtol=1e-11, atol=1e-14)
+    # the link table the reference loaded, measured by the reference: the sample taken on that configuration
+    last = full[stop - 1]
+    assert abs(check["Plq_spat"] - last[col["Plq_spat"]]) < 1e-11 and abs(check["Plq_temp"] - last[col["Plq_temp"]]) < 1e-11
+    assert abs(check["S_spat"] - last[col["S_spat"]]) < 1e-10 and abs(check["S_temp"] - last[col["S_temp"]]) < 1e-10
+    if head["PL_level"] > 0:
+        assert abs(check["Polyakov_loop"] - last[col["Polyakov_loop"]]) < 1e-11
+        assert abs(check["Polyakov_loop_im"] - last[col["Polyakov_loop_im"]]) < 1e-11
+    if "GETWILSON" in keys:
+        assert abs(check["Wilson_loop"] - last[col["Wilson_loop"]]) < 1e-11
+    # kept for the record under gpurun_out/ (scratch): the files and what the reference's reader said about them
+    keep = os.path.join(ROOT, "gpurun_out", "qcg")
+    os.makedirs(keep, exist_ok=True)
+    import shutil
+    shutil.copy(qcg, os.path.join(keep, case + ".qcg"))
+    with open(os.path.join(keep, case + ".json"), "w") as f:
+        json.dump({"init": keys, "header": head, "samples": samples, "reference_remeasurement": check,
+                   "result_table_fields": fields, "result_table_row_at_save": [float(x) for x in last]}, f, indent=1)
 
 
 def test_cli_state_file_with_fmunu_sections(tmp_path):

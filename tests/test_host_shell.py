@@ -155,3 +155,51 @@ def test_gid_tables_match_checker():
     r = q.host_gid_randoms(1234, 10, 65536)
     assert np.all((r >= 0) & (r <= 1))
     lat.close()
+
+
+QCG_DIR = os.path.join(ROOT, "tests", "golden", "qcg")
+QCG_CHECK = os.path.join(ROOT, "oracle", "_ref", "qcdgpu_qcg_check")
+
+
+@pytest.mark.parametrize("case", ["su3_plain", "su3_fmunu_wilson", "su3_f0mu_twist_hot", "su2_plain", "su2_wilson_nopl"])
+def test_committed_state_files_against_the_reference_reader(case):
+    """State files this engine's host wrote on the GPU box (tests/test_gpu_host.py keeps them), committed with what
+    the reference's own reader and CPU re-measurement said about them (oracle/ref_qcg_driver.cpp over
+    model::lattice_load_state, SU(N)/suncl/suncl.cpp:1990-2079).  Without a GPU: the header words are where the
+    reference's lattice_make_bin_header puts them (:1939-1988), the sections have the lengths the header announces, and
+    -- where the reference reader is built -- it reads the committed file to the committed numbers again."""
+    import json
+    import struct
+    import subprocess
+    doc = json.load(open(os.path.join(QCG_DIR, case + ".json")))
+    raw = open(os.path.join(QCG_DIR, case + ".qcg"), "rb").read()
+    head = struct.unpack("<64I", raw[:256])
+    want, keys = doc["header"], doc["init"]
+    assert raw[:6] == b"QCDGPU" and raw[8:11] == b"1.5"
+    assert head[5] == want["ints"] and head[6] == want["randseries"] and head[7] == want["generator"] and head[8] == want["nskip"]
+    assert head[10:16] == (want["NAV"], want["NAV_counter"], want["NITER"], want["ITER"], want["ITER_counter"], want["NHIT"])
+    assert struct.unpack("<d", raw[19 * 4:21 * 4])[0] == keys["BETA"]
+    assert head[36:38] == (want["group"], 4) and list(head[38:42]) == want["L"] == list(head[42:46])
+    assert head[63] in (1, 2, 4)          # sites per random stream, in a word the reference leaves zero and does not read
+    es, esf, pls = head[33], head[34], head[35]
+    sites = int(np.prod(want["L"]))
+    rows, rs = (12 if want["group"] == 3 else 4), (1 + (sites - 1) // 256) * 256
+    plq = want["get_plaquettes_avr"] or want["get_Fmunu"] or keys.get("F0MU", 0)
+    off = 256 + 16 * es + (16 * esf if plq else 0) + (8 * es if want["get_wilson_loop"] else 0) + (16 * pls if want["PL_level"] > 0 else 0)
+    assert raw[off + rows * rs * 32:off + rows * rs * 32 + 7] == b"QCDRLX1"      # this engine's generator states follow the reference's file
+    table = np.frombuffer(raw[off:off + rows * rs * 32], dtype=np.float64).reshape(rows, rs, 4)
+    if want["group"] == 3:
+        u = table[0:4, :sites, :3] + 1j * table[4:8, :sites, :3]       # first rows of the links (su3_matrix_memory.cl:42-176)
+        assert np.max(np.abs(np.sum(np.abs(u) ** 2, axis=2) - 1)) < 1e-13
+    if not os.path.exists(QCG_CHECK):
+        pytest.skip("oracle/_ref/qcdgpu_qcg_check is not built here")
+    r = subprocess.run([QCG_CHECK, os.path.join(QCG_DIR, case + ".qcg"), str(keys.get("F0MU", 0))], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = {ln.split()[0]: ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("check_")}
+    for name, value in doc["reference_remeasurement"].items():
+        assert abs(float(got["check_" + name][0]) - value) <= 1e-14 * max(1.0, abs(value)), name
+    # ... and the re-measured plaquette is the result table's row of the configuration the file holds
+    f = doc["result_table_fields"]
+    row = doc["result_table_row_at_save"]
+    assert abs(doc["reference_remeasurement"]["Plq_spat"] - row[f.index("Plq_spat")]) < 1e-11
+    assert abs(doc["reference_remeasurement"]["Plq_temp"] - row[f.index("Plq_temp")]) < 1e-11
