@@ -543,6 +543,7 @@ void model::derive_sample(int index)
 //   GLOBAL stream order, so a file written by a run cut into parts loads into any other cut.
 
 static const unsigned int BIN_HEADER_SIZE = 64;     // suncl.cpp:60
+static const int MAX_SAMPLES = 1 << 22;             // ITER beyond this is refused (every sample series is held in memory)
 static const unsigned int SIZE_ALIGN = 256;         // buffer_size_align step (clinterface.cpp:1580-1590): workgroup size
 static unsigned int size_align(unsigned int n) { return (1 + (n - 1) / SIZE_ALIGN) * SIZE_ALIGN; }
 static unsigned int convert_str_uint(const char* str, unsigned int offset)   // suncl.cpp:709-716
@@ -673,6 +674,21 @@ bool model::lattice_load_bin_header(const unsigned int* head)   // suncl.cpp:199
     // (zero in a file the reference wrote: one stream per site pair, and no generator states to lay out)
     const unsigned int share = head[BIN_HEADER_SIZE - 1];
     if (share == 1 || share == 2 || share == 4) RNGSHARE = (int)share;
+    // A header is trusted with the size of everything that is allocated next: words that no run of this program or of
+    // the reference can have written make it a bad header, not a request for memory
+    if (ITER < 1 || ITER > MAX_SAMPLES || ITER_counter < 0 || ITER_counter > ITER || NAV < 0 || NAV_counter < 0 || NAV_counter > NAV || NITER < 0 ||
+        NHIT < 1 || NHIT > 4096 || wilson_R < 0 || wilson_T < 0 || wilson_R > 4096 || wilson_T > 4096)
+        return false;
+    if (lattice_group != 2 && lattice_group != 3) return false;
+    unsigned long long sites = 1;
+    for (int i = 0; i < 4; i++) {
+        if (lattice_full_size[i] < 2 || lattice_full_size[i] > 4096 || lattice_domain_size[i] != lattice_full_size[i]) return false;
+        sites *= (unsigned long long)lattice_full_size[i];
+    }
+    if (sites > (1ull << 30)) return false;
+    if (state_sizes_[1] != energies_size() || (state_sizes_[2] != state_sizes_[1] && state_sizes_[2] != 7u * state_sizes_[1]) ||
+        state_sizes_[3] != state_sizes_[1] || state_sizes_[0] > 7ull * (sites + 4096))
+        return false;
     return true;
 }
 
@@ -774,7 +790,7 @@ void model::lattice_save_state(void)
         for (const std::vector<double>* v : {&s_diff_[a], &pl_diff_[a], &pl_diff_im_[a]}) {
             const unsigned long long len = v->size();
             fwrite(&len, sizeof(len), 1, stream);
-            fwrite(v->data(), sizeof(double), v->size(), stream);
+            if (len) fwrite(v->data(), sizeof(double), v->size(), stream);   // (an empty series has no storage to point at)
         }
     if (fclose(stream)) printf("The file was not closed!\n");
     time(&last_save_);
@@ -922,8 +938,9 @@ void model::lattice_load_state(void)
             for (std::vector<double>* v : {&s_diff_[a], &pl_diff_[a], &pl_diff_im_[a]}) {
                 unsigned long long len = 0;
                 if (fread(&len, sizeof(len), 1, stream) != 1) { profiles_read = false; break; }
+                if (len > 64ull * (unsigned long long)ITER) { profiles_read = false; break; }   // not a length this program writes
                 std::vector<double> tmp((size_t)len);
-                if (fread(tmp.data(), sizeof(double), tmp.size(), stream) != tmp.size()) { profiles_read = false; break; }
+                if (len && fread(tmp.data(), sizeof(double), tmp.size(), stream) != tmp.size()) { profiles_read = false; break; }
                 if (v->empty()) continue;                       // series not asked for in this run
                 if (tmp.size() != v->size()) { profiles_read = false; break; }   // asked for, but not in the file
                 *v = tmp;
@@ -945,6 +962,8 @@ void model::lattice_simulate(void)
 {
     if (SubLat.empty() || !SubLat[0].ctx) throw model_error("lattice_simulate before lattice_init");
     if (ITER < 1) throw model_error("ITER < 1");
+    if (ITER > MAX_SAMPLES) throw model_error("ITER beyond 2^22 samples: every sample series is held in memory");
+    if (NAV < 0 || NITER < 0) throw model_error("NAV or NITER negative");
     for (int i = 0; i < 3; i++) {
         plq_[i].assign(ITER, 0.0);
         act_[i].assign(ITER, 0.0);
