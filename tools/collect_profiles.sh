@@ -6,8 +6,10 @@ set -u
 OUT=$(realpath -m "$1"); mkdir -p "$OUT"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
+# the command the round-end bench uses (--steps 20 --warmup 5), so that the kernel averages can be held against its line
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 20 --no-cpu > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log" || { echo "stats failed"; tail -5 "$OUT/stats.log"; exit 1; }
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log" || { echo "stats failed"; tail -5 "$OUT/stats.log"; exit 1; }
+python3 "$ROOT/tools/kernel_stats_split.py" "$(find "$OUT/stats" -name 'bench_kernel_trace.csv' | head -1)" 5 20 5 > "$OUT/kernel_stats_split.json" || exit 1
 echo "stats ok"
 bash "$ROOT/tools/collect_pmc.sh" "$OUT/pmc" || exit 1
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc" > "$OUT/pmc_summary.json" || exit 1
