@@ -82,17 +82,19 @@ def test_rank_ring_world_of_one(tmp_path):
 def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher: the process starts two ranks as children and
     prints rank 0's JSON line (both ranks on device 0, gloo staging: the one-GPU rehearsal switches)."""
-    env = dict(os.environ, QCDGPU_BENCH_SHARE_DEVICE="1", QCDGPU_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env = dict(os.environ, QCDGPU_BENCH_SHARE_DEVICE="1", QCDGPU_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1",
+               QCDGPU_BENCH_FORCE_CROSSCHECK="1")   # ... and the cross-check of the first sweeps that a multi-GPU run makes
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2",
                         "--brackets", "2", "--L", "16", "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     doc = json.loads(line)
-    assert doc["n_gpus"] == 2 and doc["config"]["lattice"] == [32, 16, 16, 16]
+    assert doc["n_gpus"] == 2 and doc["config"]["lattice"] == [32, 16, 16, 16] and doc["scaling"] == "weak"
+    assert doc["mean_plaquette"]["parity_check"]["ok"], doc["mean_plaquette"]["parity_check"]
     assert doc["value"] > 0 and doc["roofline"]["launches"] >= 16
-    # 5 sweeps of 32 x 16^3 from a cold start at beta = 6: the plaquette has left 3 and is still above its equilibrium value
+    # 6 sweeps of 32 x 16^3 from a cold start at beta = 6: the plaquette has left 3 and is still above its equilibrium value
     assert 1.7 < doc["mean_plaquette"]["Plq_total"] < 2.2
 
 
