@@ -290,6 +290,10 @@ int  qcd_ring_create(qcd_ring **out, qcd_ctx *const *parts, int nparts, int tran
 int  qcd_rccl_unique_id(void *id, size_t bytes);
 int  qcd_ring_create_rank(qcd_ring **out, qcd_ctx *part, int rank, int world, const void *id, size_t bytes);
 void qcd_ring_destroy(qcd_ring *ring);
+/* n sweeps the way the reference's CHB2 build runs its working cycles (suncl.cpp:4683-4729): every part runs the eight
+ * passes of a sweep without an exchange, then the edges of all four directions are copied once.  Halos are up to a sweep
+ * old inside a sweep: not the uncut lattice's chain at the slab faces, one round of messages per sweep instead of eight. */
+int  qcd_ring_sweep_chb2(qcd_ring *ring, int n);
 int  qcd_ring_update(qcd_ring *ring, int parity, int dir);
 int  qcd_ring_overrelax(qcd_ring *ring, int parity, int dir);
 int  qcd_ring_sweep(qcd_ring *ring, int n);

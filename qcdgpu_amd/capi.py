@@ -59,7 +59,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_precision", "qcd_
            "qcd_on_timed_sweeps", "qcd_on_measure", "qcd_on_counters", "qcd_on_max_u", "qcd_on_upload",
            "qcd_on_download", "qcd_measure_plaquette_sums_static", "qcd_get_stream", "qcd_get_params", "qcd_update_kernel", "qcd_rng_share_for",
            "qcd_ring_create", "qcd_rccl_unique_id", "qcd_ring_create_rank", "qcd_ring_destroy", "qcd_ring_update",
-           "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_fill_halos", "qcd_ring_synchronize", "qcd_ring_one_launch_passes"]
+           "qcd_ring_overrelax", "qcd_ring_sweep", "qcd_ring_sweep_chb2", "qcd_ring_fill_halos", "qcd_ring_synchronize", "qcd_ring_one_launch_passes"]
 
 
 def _load(path=None):
@@ -105,6 +105,7 @@ def _load(path=None):
     lib.qcd_ring_update.argtypes = [P, I, I]
     lib.qcd_ring_overrelax.argtypes = [P, I, I]
     lib.qcd_ring_sweep.argtypes = [P, I]
+    lib.qcd_ring_sweep_chb2.argtypes = [P, I]
     lib.qcd_ring_fill_halos.argtypes = [P]
     lib.qcd_ring_synchronize.argtypes = [P]
     lib.qcd_ring_one_launch_passes.argtypes = [P, C.POINTER(C.c_ulonglong)]
@@ -416,6 +417,10 @@ class Ring:
 
     def sweep(self, n=1):
         _check(self.lib.qcd_ring_sweep(self.h, n), self.lib)
+
+    def sweep_chb2(self, n=1):
+        """n sweeps with ONE edge exchange per sweep (the reference's CHB2 build): not the uncut lattice's chain."""
+        _check(self.lib.qcd_ring_sweep_chb2(self.h, n), self.lib)
 
     def fill_halos(self):
         _check(self.lib.qcd_ring_fill_halos(self.h), self.lib)

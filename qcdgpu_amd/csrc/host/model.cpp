@@ -157,6 +157,7 @@ void model::lattice_get_init_file(char* file)
         if (!strcmp(v, "OMEGA")) OMEGA = p.fVarVal;
         if (!strcmp(v, "NAV")) NAV = p.iVarVal;
         if (!strcmp(v, "NOVERRELAX")) NOVERRELAX = p.iVarVal;   // extension: the reference has no overrelaxation
+        if (!strcmp(v, "CHB2")) CHB2 = p.iVarVal != 0;          // the reference's build flag -D CHB2 (SU(N)/Makefile:5-20) as a key
         if (!strcmp(v, "RNGSHARE")) RNGSHARE = p.iVarVal;       // extension: sites per RANLUX stream (qcd_params::rng_share)
         if (!strcmp(v, "INTS"))
             ints = (p.iVarVal == 0) ? model_start_hot : (p.iVarVal == 2 ? model_start_gid : model_start_cold);
@@ -372,9 +373,15 @@ void model::UpdateEdges(int dir, int parity)
 
 // one sweep in the reference order: odd X,Y,Z,T then even X,Y,Z,T, edges after every pass
 // (SU(N)/suncl/suncl.cpp:5357-5377 and :5026-5138); re-unitarisation is part of the update kernel
-void model::sweep(void)
+void model::sweep(bool working)
 {
     if (turnoff_updates) return;
+    if (ring && CHB2 && working && NOVERRELAX == 0) {
+        // the reference's -D CHB2 build: in the working cycles the edges are copied once per sweep (suncl.cpp:4683-4729)
+        check(qcd_ring_sweep_chb2(ring, 1), "qcd_ring_sweep_chb2");
+        PRNG_counter += 8;
+        return;
+    }
     for (int parity = 1; parity >= 0; parity--)
         for (int dir = 0; dir < 4; dir++) {
             if (ring) {
@@ -1008,7 +1015,7 @@ void model::lattice_simulate(void)
     }
     // working cycles (suncl.cpp:5390-5495)
     for (int i = ITER_counter; i < ITER; i++) {
-        for (int j = 0; j < NITER; j++) sweep();
+        for (int j = 0; j < NITER; j++) sweep(true);
         if (i % 10 == 0) printf("\rGPU working iteration [%u]", i);
         measure(ITER_counter++);
         if (!turnoff_config_save && difftime(time(NULL), last_save_) > write_lattice_state_every_secs) {

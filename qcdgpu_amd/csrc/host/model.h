@@ -117,6 +117,7 @@ public:
     int NHIT = 10;
     int NHITPar = 1;
     int NOVERRELAX = 0;   // overrelaxation sweeps after every heat-bath sweep (not in the reference)
+    bool CHB2 = false;    // BigLattice working cycles with one edge exchange per sweep (the reference's -D CHB2 build)
     int RNGSHARE = 0;     // sites of one parity per RANLUX stream (1, 2, 4; 0: chosen by the library from the lattice size)
     double BETA = 6.5;
     double PHI = 0.0;
@@ -203,7 +204,7 @@ private:
     std::vector<double> plq_raw_[2], pl_raw_[4];   // per sample: the lattice sums the table entries derive from
     void derive_sample(int index);
     std::string device_names_;
-    void sweep(void);
+    void sweep(bool working = false);   // working: a sweep of the working cycles (the CHB2 variant applies there only)
     void measure(int index);
     void check(int rc, const char* what);
     unsigned int LOAD_state = 0;

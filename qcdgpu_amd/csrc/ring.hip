@@ -684,6 +684,39 @@ int qcd_ring_sweep(qcd_ring* r, int n)
     return QCD_OK;
 }
 
+// The reference's CHB2 build (SU(N)/suncl/suncl.cpp:4683-4729): in its working cycles every part runs the eight passes of
+// a sweep on its own and the edges of all four directions are copied once, behind the sweep.  Inside the sweep a part
+// reads halos that are up to a sweep old, so the chain differs from the uncut lattice's at the slab faces (it is the
+// reference's variant, reproduced as it is); in exchange a sweep costs one round of messages instead of eight.
+int qcd_ring_sweep_chb2(qcd_ring* r, int n)
+{
+    if (!r) return failf(QCD_ERR_INVALID, "null ring");
+    if (n < 0) return failf(QCD_ERR_INVALID, "negative sweep count");
+    for (int s = 0; s < n; s++) {
+        int rc = for_parts(r, [=](int k) -> int {
+            Part& p = r->parts[k];
+            void* st = nullptr;
+            int rc2 = qcd_get_stream(p.ctx, &st);
+            if (rc2) return rc2;
+            p.stream = (hipStream_t)st;
+            RING_HIP(hipSetDevice(p.device));
+            for (int parity = 1; parity >= 0; parity--)      // SU(N)/suncpp/suncpp.h:133-141: odd X,Y,Z,T then even
+                for (int dir = 0; dir < 4; dir++)
+                    if ((rc2 = qcd_update(p.ctx, parity, dir))) return rc2;
+            RING_HIP(hipEventRecord(p.edge_done, p.stream));
+            RING_HIP(hipStreamWaitEvent(p.lane, p.edge_done, 0));
+            RING_HIP(hipEventRecord(p.ready, p.lane));
+            return QCD_OK;
+        });
+        if (rc) return rc;
+        for (int dir = 0; dir < 4; dir++)
+            for (int parity = 0; parity < 2; parity++)
+                if ((rc = exchange(r, parity, dir, 2))) return rc;
+        r->passes += 8;
+    }
+    return QCD_OK;
+}
+
 int qcd_ring_fill_halos(qcd_ring* r)
 {
     if (!r) return failf(QCD_ERR_INVALID, "null ring");

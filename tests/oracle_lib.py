@@ -27,6 +27,8 @@ def _load():
     lib.qo_create.argtypes = [I, pi, D, I, I, I, I, U]
     lib.qo_set_twist.argtypes = [P, D, D]
     lib.qo_set_twist.restype = None
+    lib.qo_update_pass_range.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.qo_update_pass_range.restype = None
     lib.qo_set_rng_share.argtypes = [P, C.c_int]
     lib.qo_set_rng_share.restype = C.c_int
     lib.qo_destroy.argtypes = [P]
@@ -114,6 +116,10 @@ class Lattice:
 
     def update(self, parity, direction):
         lib.qo_update_pass(self.h, parity, direction)
+
+    def update_range(self, parity, direction, x_begin, x_end):
+        """The pass restricted to the sites with x in [x_begin, x_end): what one slab of a cut lattice does."""
+        lib.qo_update_pass_range(self.h, parity, direction, x_begin, x_end)
 
     def overrelax(self, parity, direction):
         lib.qo_overrelax_pass(self.h, parity, direction)

@@ -586,6 +586,67 @@ def test_ring_over_rccl_on_one_gpu(by_rank):
         lat.close()
 
 
+@pytest.mark.parametrize("group,L,parts,beta", [(3, (8, 4, 4, 6), [4, 4], 5.8), (2, (12, 4, 6, 4), [4, 6, 2], 2.4)])
+def test_ring_sweep_with_one_exchange_per_sweep(group, L, parts, beta):
+    """qcd_ring_sweep_chb2, the reference's CHB2 build (SU(N)/suncl/suncl.cpp:4683-4729): eight passes per part on halos
+    that are as old as the last sweep, then one exchange of all edges.  Emulated with the checker: one full-size
+    lattice per part in which only the part's slices are updated (qo_update_pass_range reads the part's own, stale copies
+    of its neighbours' boundary slices), the boundary slices copied between the lattices behind every sweep.  Not the
+    uncut lattice's chain -- which the test checks as well."""
+    import qcdgpu_amd as q
+    nparts = len(parts)
+    x0s = [sum(parts[:k]) for k in range(nparts)]
+    lats = [ol.Lattice(group, L, beta, nhit=6, ints=1, rng_mode=ol.RNG_PERSITE, seed=37) for _ in parts]
+    whole = ol.Lattice(group, L, beta, nhit=6, ints=1, rng_mode=ol.RNG_PERSITE, seed=37)
+    ctxs = [q.Context(group=group, L=L, beta=beta, nhit=6, rand_series=37, x0=x0s[k], nx_local=parts[k], halo=1) for k in range(nparts)]
+    for c in ctxs:
+        c.init_lattice()
+    ring = q.Ring(ctxs, q.RING_COPY)
+    gslice = L[1] * L[2] * L[3]
+    try:
+        for s in range(3):
+            ring.sweep_chb2(1)
+            whole.sweep(1)
+            for k, lat in enumerate(lats):
+                for parity in (1, 0):
+                    for d in range(4):
+                        lat.update_range(parity, d, x0s[k], x0s[k] + parts[k])
+            tabs = [lat.export_table() for lat in lats]
+            for k in range(nparts):
+                left, right = (k - 1) % nparts, (k + 1) % nparts
+                xl, xr = (x0s[k] - 1) % L[0], (x0s[k] + parts[k]) % L[0]
+                tabs[k][:, xl * gslice:(xl + 1) * gslice] = lats[left].export_table()[:, xl * gslice:(xl + 1) * gslice]
+                tabs[k][:, xr * gslice:(xr + 1) * gslice] = lats[right].export_table()[:, xr * gslice:(xr + 1) * gslice]
+            for k, lat in enumerate(lats):
+                lat.import_table(tabs[k])
+            got = np.concatenate([c.download() for c in ctxs], axis=1)
+            want = np.concatenate([lats[k].export_table()[:, x0s[k] * gslice:(x0s[k] + parts[k]) * gslice] for k in range(nparts)], axis=1)
+            assert np.max(np.abs(got - want)) < 1e-11, s
+            assert sum(c.rng_draws() for c in ctxs) == sum(ol.rng_draws(lat) for lat in lats), s
+        assert np.max(np.abs(got - whole.export_table())) > 1e-3      # a different chain from the first sweep's faces on
+    finally:
+        ring.close()
+        for c in ctxs:
+            c.close()
+        for lat in lats + [whole]:
+            lat.close()
+
+
+def test_cli_chb2_key_switches_the_working_cycles(tmp_path):
+    """The reference's build flag -D CHB2 as an init key of the host: thermalisation sweeps exchange edges per pass as
+    always, the working cycles once per sweep (SU(N)/suncl/suncl.cpp:4683-4729) -- so the sample behind the
+    thermalisation is the same with and without the key and the later ones are not."""
+    keys = dict(GROUP=3, ND=4, L1=8, L2=4, L3=4, L4=6, BETA=5.8, NHIT=4, INTS=1, PRNG="RANLUX3", RANDSERIES=41, NAV=2, ITER=5, NITER=1,
+                N1="{4, 4}", DEVICE="{0, 0}")
+    _, fields, plain, _ = _run(tmp_path / "a", keys)
+    _, _, lazy, _ = _run(tmp_path / "b", dict(keys, CHB2=1))
+    i = fields.index("Plq_total")
+    assert plain[0, i] == lazy[0, i] == 3.0
+    assert plain[1, i] != lazy[1, i] and abs(plain[4, i] - lazy[4, i]) < 0.1      # another chain of the same physics
+    _, _, uncut, _ = _run(tmp_path / "c", dict({k: v for k, v in keys.items() if k not in ("N1", "DEVICE")}, CHB2=1))
+    assert np.array_equal(uncut, _run(tmp_path / "d", {k: v for k, v in keys.items() if k not in ("N1", "DEVICE")})[2])   # no parts: no effect
+
+
 @pytest.mark.parametrize("threads", ["1", "0"])
 def test_ring_of_eight_parts_one_host_thread_per_part(threads, monkeypatch):
     """Eight parts driven by one process, as the reference's BigLattice on an 8-GPU node (one OpenMP thread per device,

@@ -19,6 +19,8 @@ for k in range(nparts):
     c.init_lattice()
     ctxs.append(c)
 ring = q.Ring(ctxs, q.RING_COPY)
+if os.environ.get("RING_CHB2"):       # one exchange per sweep (the reference's CHB2 build) instead of one per pass
+    ring.sweep = ring.sweep_chb2
 ring.sweep(3)
 ring.synchronize()
 n = 20
