@@ -161,6 +161,13 @@ int qcd_ring_update(qcd_ring* r, int parity, int dir)
     }
     return QCD_OK;
 }
+int qcd_ring_sweep_chb2(qcd_ring* r, int n)
+{
+    for (int s = 0; s < n; s++)
+        for (int parity = 1; parity >= 0; parity--)
+            for (int dir = 0; dir < 4; dir++) qcd_ring_update(r, parity, dir);
+    return QCD_OK;
+}
 int qcd_ring_overrelax(qcd_ring* r, int parity, int dir)
 {
     for (qcd_ctx* c : r->parts) qcd_overrelax(c, parity, dir);

@@ -69,7 +69,7 @@ def _keys(d):
 
 def test_host_runs_and_resumes_clean(host, tmp_path):
     for extra in ({}, dict(GETWILSON=1, WILSONR=2, WILSONT=2, FMUNU=1, FMUNU2=1), dict(F0MU=1, PL_LEVEL=0), dict(GROUP=2, GETSDIFF=1),
-                  dict(L1=8, N1="{4, 2, 2}", DEVICE="{0, 0, 0}")):
+                  dict(L1=8, N1="{4, 2, 2}", DEVICE="{0, 0, 0}"), dict(L1=8, N1="{4, 4}", DEVICE="{0, 0}", CHB2=1, NOVERRELAX=0)):
         keys = dict(BASE, **extra)
         name = "run%d" % len(extra)
         rc, out = _run(host, tmp_path / name, _keys(keys))
