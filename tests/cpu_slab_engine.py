@@ -17,9 +17,9 @@ ol.lib.qo_polyakov_sums_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTE
 
 
 class CpuSlabEngine:
-    def __init__(self, group, L, beta, x0, nx, nhit=10, lux=3, seed=54, ints=1):
+    def __init__(self, group, L, beta, x0, nx, nhit=10, lux=3, seed=54, ints=1, share=1):
         mode = ol.RNG_GID if ints == 2 else ol.RNG_PERSITE
-        self.lat = ol.Lattice(group, L, beta, nhit=nhit, ints=ints, rng_mode=mode, lux=lux, seed=seed)
+        self.lat = ol.Lattice(group, L, beta, nhit=nhit, ints=ints, rng_mode=mode, lux=lux, seed=seed, share=share)
         self.L, self.x0, self.nx = tuple(L), x0, nx
         self.slice = L[1] * L[2] * L[3]
         reals = 18 if group == 3 else 8

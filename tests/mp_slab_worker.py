@@ -20,7 +20,7 @@ def main():
     parts = cfg.get("parts") or bl.split_even(L[0], world)
     x0 = sum(parts[:rank])
     eng = CpuSlabEngine(cfg["group"], L, cfg["beta"], x0, parts[rank], nhit=cfg["nhit"], seed=cfg["seed"],
-                        ints=cfg["ints"])
+                        ints=cfg["ints"], share=cfg.get("share", 1))
     lat = bl.BigLattice([eng], bl.TorchDistComm(eng, rank, world), cfg["group"], L, cfg["beta"])
     if cfg["ints"] == 0:
         lat.fill_halos()

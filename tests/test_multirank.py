@@ -37,7 +37,7 @@ def _run(world, cfg, tmp_path):
 def _single(cfg):
     mode = ol.RNG_GID if cfg["ints"] == 2 else ol.RNG_PERSITE
     lat = ol.Lattice(cfg["group"], cfg["L"], cfg["beta"], nhit=cfg["nhit"], ints=cfg["ints"], rng_mode=mode,
-                     seed=cfg["seed"])
+                     seed=cfg["seed"], share=cfg.get("share", 1))
     rows = [np.concatenate([lat.plaquette(), lat.action(), lat.polyakov()])]
     for _ in range(cfg["sweeps"]):
         lat.sweep(1)
@@ -53,6 +53,9 @@ def _single(cfg):
     (3, dict(group=3, L=[8, 4, 4, 4], beta=5.5, nhit=3, seed=9, ints=1, sweeps=1, parts=[2, 4, 2])),
     (2, dict(group=3, L=[8, 4, 4, 4], beta=5.8, nhit=4, seed=21, ints=0, sweeps=1)),   # hot start
     (2, dict(group=2, L=[16, 4, 4, 4], beta=2.3, nhit=5, seed=3, ints=1, sweeps=2)),   # boundary slices two deep
+    # random streams shared by 2 and by 4 sites of one parity: the stream of a site does not depend on the cut
+    (2, dict(group=3, L=[8, 4, 4, 4], beta=6.0, nhit=10, seed=54, ints=1, sweeps=2, share=2)),
+    (3, dict(group=2, L=[8, 4, 4, 8], beta=2.3, nhit=5, seed=11, ints=0, sweeps=1, parts=[2, 4, 2], share=4)),
 ])
 def test_gloo_ranks_reproduce_single_process_run(world, cfg, tmp_path):
     got = _run(world, cfg, tmp_path)
