@@ -857,6 +857,33 @@ __host__ __device__ constexpr int staple_aux(int mu, int nu, int which)
     const int k = nu < mu ? nu : nu - 1;
     return ((nt_mask(mu) >> (3 * which + k)) & 1u) ? AUX_NT : ((which == 1 || which == 3) ? 0 : QCD_NU_AUX);
 }
+#ifdef QCD_ABL_DROP   // diagnostic build: the requests named by the mask (bit = `which` above) are not made (unit link instead)
+template <int WHICH, int AUX>
+__device__ __forceinline__ raw_link issue_or_drop(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off)
+{
+    if (((QCD_ABL_DROP) >> WHICH) & 1) {
+        raw_link l;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            l.c[c].x = (c == 0 || c == 4) ? real(1) : real(0);
+            l.c[c].y = real(0);
+        }
+        return l;
+    }
+    return issue_link<AUX>(r, g, byte_off);
+}
+#else
+template <int WHICH, int AUX>
+__device__ __forceinline__ raw_link issue_or_drop(__amdgpu_buffer_rsrc_t r, const Geom& g, int byte_off)
+{
+    return issue_link<AUX>(r, g, byte_off);
+}
+#endif
+#ifdef QCD_ABL_MU_SAME   // diagnostic build: the six requests for U_mu(x +- nu) all go to the block's own index
+#define QCD_MU_OFF(o) 0
+#else
+#define QCD_MU_OFF(o) (o)
+#endif
 template <int DIR, int TERM>
 __device__ __forceinline__ raw_pair issue_ab(const real2* __restrict__ U, const Geom& g, const int hb,
                                              const NbrOff& n, const int par)
@@ -866,12 +893,12 @@ __device__ __forceinline__ raw_pair issue_ab(const real2* __restrict__ U, const 
     const int fmu = off_fwd(n, DIR);
     raw_pair t;
     if (TERM % 2 == 0) {
-        t.a = issue_link<staple_aux(DIR, nu, 0)>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + fmu);
-        t.b = issue_link<staple_aux(DIR, nu, 1)>(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + off_fwd(n, nu));
+        t.a = issue_or_drop<0, staple_aux(DIR, nu, 0)>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + fmu);
+        t.b = issue_or_drop<1, staple_aux(DIR, nu, 1)>(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + QCD_MU_OFF(off_fwd(n, nu)));
     } else {
         const int bnu = off_bwd(n, nu);
-        t.a = issue_link<staple_aux(DIR, nu, 3)>(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + bnu);
-        t.b = issue_link<staple_aux(DIR, nu, 4)>(link_rsrc<3>(U, g, nu, par), g, hb + bnu + fmu);
+        t.a = issue_or_drop<3, staple_aux(DIR, nu, 3)>(link_rsrc<3>(U, g, DIR, par ^ 1), g, hb + QCD_MU_OFF(bnu));
+        t.b = issue_or_drop<4, staple_aux(DIR, nu, 4)>(link_rsrc<3>(U, g, nu, par), g, hb + bnu + fmu);
     }
     return t;
 }
@@ -881,8 +908,8 @@ __device__ __forceinline__ raw_link issue_c(const real2* __restrict__ U, const G
 {
     constexpr int k = TERM / 2;
     constexpr int nu = (k < DIR) ? k : k + 1;
-    if (TERM % 2 == 0) return issue_link<staple_aux(DIR, nu, 2)>(link_rsrc<3>(U, g, nu, par), g, hb);
-    return issue_link<staple_aux(DIR, nu, 5)>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_bwd(n, nu));
+    if (TERM % 2 == 0) return issue_or_drop<2, staple_aux(DIR, nu, 2)>(link_rsrc<3>(U, g, nu, par), g, hb);
+    return issue_or_drop<5, staple_aux(DIR, nu, 5)>(link_rsrc<3>(U, g, nu, par ^ 1), g, hb + off_bwd(n, nu));
 }
 // first product of a term: two rows of a * b^+ (forward) or of a * b (backward)
 template <int TERM>
