@@ -1327,7 +1327,22 @@ struct GhShared {
     unsigned full_seq[TEAMS][GH_SLOTS][PER];                // gather wavefront j has put block (full_seq - 1) into the slot
     unsigned free_seq[TEAMS][GH_SLOTS];                     // the heat-bath side has read block (free_seq - 1) out of the slot
     unsigned simd_count[4];
+#ifdef QCD_GH_SYNC
+    unsigned gsync;                                         // experimental: arrivals of the gather wavefronts at their common steps
+#endif
 };
+#ifdef QCD_GH_SYNC   // experimental build: the gather wavefronts of a workgroup start every block (1) or every term (2) together
+__device__ __forceinline__ void gh_sync(unsigned* ctr, unsigned& epoch, const int lane)
+{
+    epoch++;
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)GH_SIDE * epoch) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void gh_sync_leave(unsigned* ctr, const int lane)
+{
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u << 24, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#endif
 
 // the team's it-th block of sites: workgroup b works for region b % regions, the teams of the
 // workgroups of a region take consecutive groups of its blocks (the `share` blocks whose sites share their random
@@ -1357,6 +1372,10 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
     QCD_GH_SPIN_DECL;
     const int parity = a.parity;
     int wb = gh_block<TEAMS>(g, a.nblocks, team, 0, a.reverse);
+#ifdef QCD_GH_SYNC
+    unsigned epoch = 0;
+    if (wb < 0) gh_sync_leave(&sh.gsync, lane);
+#endif
     if (wb < 0) return;
     SiteRef cur = site_ref<64>(g, wb, lane, parity);
     raw_pair ab = issue_ab<DIR, T0>(a.U, g, cur.hb, cur.nbr, parity);
@@ -1368,12 +1387,21 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
         SiteRef nxt = cur;
         if (has_next) nxt = site_ref<64>(g, wbn, lane, parity);
         su3 stap = zero<3>();
+#if defined(QCD_GH_SYNC) && QCD_GH_SYNC == 1
+        gh_sync(&sh.gsync, epoch, lane);
+#endif
+#if defined(QCD_GH_SYNC) && QCD_GH_SYNC == 2
+#define QCD_GH_TERM_SYNC gh_sync(&sh.gsync, epoch, lane);
+#else
+#define QCD_GH_TERM_SYNC
+#endif
 #define QCD_GH_TERM(K)                                                                                   \
         if (K < NT) {                                                                                    \
             constexpr int T = T0 + (K < NT ? K : 0), TN = T0 + (K + 1 < NT ? K + 1 : 0);                 \
             pin(ab);                                                                                     \
             rows2 p = first_product<T>(ab);                                                              \
             pin(p);                                                                                      \
+            QCD_GH_TERM_SYNC                                                                             \
             if (K + 1 < NT) ab = issue_ab<DIR, TN>(a.U, g, cur.hb, cur.nbr, parity);                     \
             else if (has_next) ab = issue_ab<DIR, T0>(a.U, g, nxt.hb, nxt.nbr, parity);                  \
             pin(cl);                                                                                     \
@@ -1418,6 +1446,9 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
         if (!has_next) break;
         cur = nxt;
     }
+#ifdef QCD_GH_SYNC
+    gh_sync_leave(&sh.gsync, lane);
+#endif
     QCD_GH_SPIN_FLUSH(0);
 }
 
@@ -1430,6 +1461,9 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
     __shared__ Sh sh;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 4) sh.simd_count[threadIdx.x] = 0u;
+#ifdef QCD_GH_SYNC
+    if (threadIdx.x == 0) sh.gsync = 0u;
+#endif
     if (threadIdx.x < TEAMS * GH_SLOTS * PER) (&sh.full_seq[0][0][0])[threadIdx.x] = 0u;
     if (threadIdx.x < TEAMS * GH_SLOTS) (&sh.free_seq[0][0])[threadIdx.x] = 0u;
     MathFast::fill<512>(sh.logtab);
