@@ -318,6 +318,29 @@ int launch_overrelax(qcd_ctx* c, int parity, int dir)
         }
         return QCD_OK;
     }
+    if constexpr (GROUP == 3 && UPD_BLOCK == 64) {
+        // a pass with enough blocks runs through the gather / second-wavefront pairs of the heat-bath pass (k_update_gh)
+        static const bool ovr_gh = !(getenv("QCDGPU_AMD_OVR_GH") && atoi(getenv("QCDGPU_AMD_OVR_GH")) == 0);   // diagnostic override: 0 never
+        if (ovr_gh && pass_is_paired(c, g.nx)) {
+            UpdArgs a = {};
+            a.U = c->U;
+            a.g = g;
+            a.g.ux0 = 0;
+            a.g.unx = g.nx;
+            a.parity = parity;
+            a.ngroups = g.nzr * g.ntr * (int)cdiv((long)g.nx * g.region_h, UPD_BLOCK);
+            a.nblocks = a.ngroups * g.share;
+            a.phase = -1;
+            const dim3 ggrid(c->gh_grid), gblock(512);
+            switch (dir) {
+                case 0: hipLaunchKernelGGL((k_update_gh<0, 0, GH_TEAMS, true>), ggrid, gblock, 0, c->stream, a); break;
+                case 1: hipLaunchKernelGGL((k_update_gh<1, 0, GH_TEAMS, true>), ggrid, gblock, 0, c->stream, a); break;
+                case 2: hipLaunchKernelGGL((k_update_gh<2, 0, GH_TEAMS, true>), ggrid, gblock, 0, c->stream, a); break;
+                default: hipLaunchKernelGGL((k_update_gh<3, 0, GH_TEAMS, true>), ggrid, gblock, 0, c->stream, a); break;
+            }
+            return QCD_OK;
+        }
+    }
     switch (dir) {
         case 0: hipLaunchKernelGGL((k_overrelax<GROUP, 0, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, -1); break;
         case 1: hipLaunchKernelGGL((k_overrelax<GROUP, 1, UPD_BLOCK>), grid, block, 0, c->stream, c->U, g, parity, -1); break;

@@ -1452,7 +1452,9 @@ __device__ __forceinline__ void gh_gather(GhShared<TEAMS>& sh, const UpdArgs& a,
     QCD_GH_SPIN_FLUSH(0);
 }
 
-template <int DIR, int NSKIP, int TEAMS>
+// OVR: the overrelaxation pass through the same pipeline -- the second wavefront of a pair reflects the link
+// (overrelax_link) instead of drawing a new one: no generator, no random numbers, nothing counted
+template <int DIR, int NSKIP, int TEAMS, bool OVR = false>
 __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1466,7 +1468,7 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
 #endif
     if (threadIdx.x < TEAMS * GH_SLOTS * PER) (&sh.full_seq[0][0][0])[threadIdx.x] = 0u;
     if (threadIdx.x < TEAMS * GH_SLOTS) (&sh.free_seq[0][0])[threadIdx.x] = 0u;
-    MathFast::fill<512>(sh.logtab);
+    if constexpr (!OVR) MathFast::fill<512>(sh.logtab);   // the reflection takes no logarithm
     __syncthreads();
     const unsigned simd = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11))) & 3u;   // HW_ID bits 5:4
     unsigned role = 0;
@@ -1510,6 +1512,29 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
             if (wb < 0) break;
             const SiteRef cur = site_ref<64>(g, wb, lane, parity);
             const __amdgpu_buffer_rsrc_t r_own = link_rsrc<3>(a.U, g, DIR, parity);
+            if constexpr (OVR) {
+                raw_link own = issue_link<(((nt_mask(DIR) >> 18) & 1u) ? AUX_NT : 0)>(r_own, g, cur.hb);
+                const int s = it % GH_SLOTS;
+                while (__hip_atomic_load(&sh.full_seq[team][s][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(it + 1)) {
+                    __builtin_amdgcn_s_sleep(4);
+                    QCD_GH_SPIN(1);
+                }
+                static_assert(!OVR || PER == 1, "the overrelaxation pass runs as pairs of wavefronts");
+                const real2* src = &sh.stap[team][s][0][0][lane];
+                su3 A;
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const real2 v = src[k * 64];
+                    A.e[k / 3][k % 3] = mk(v.x, v.y);
+                }
+                pin(A);
+                __hip_atomic_store(&sh.free_seq[team][s], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pin(own);
+                su3 Ul = as_su3(own);
+                overrelax_link(Ul, A, fm);
+                store_link_buf(r_own, g, cur.hb, Ul);
+                continue;
+            }
             RlxFast<64, NSKIP, true> rs;
             rs.attach(a.rv, cur.stream, rcol);
             raw_link own = issue_link<(((nt_mask(DIR) >> 18) & 1u) ? AUX_NT : 0)>(r_own, g, cur.hb);

@@ -298,6 +298,54 @@ def test_overrelaxation_matches_checker_and_keeps_the_action(group, L, beta):
     lat.close()
 
 
+@pytest.mark.parametrize("share", [1, 4])
+def test_overrelaxation_through_the_pair_kernel_matches_checker(share, monkeypatch):
+    """The overrelaxation pass of large SU(3) lattices runs through the gather / second-wavefront pairs of the heat-bath
+    pass; forced here for a 16^4 lattice and compared link by link with the checker, which knows nothing of kernels."""
+    L = (16, 16, 16, 16)
+    lat = ol.Lattice(3, L, 5.9, nhit=10, ints=1, rng_mode=ol.RNG_PERSITE, seed=31, share=share)
+    monkeypatch.setenv("QCDGPU_AMD_GH", "2")
+    with _ctx(group=3, L=L, beta=5.9, nhit=10, rand_series=31, rng_share=share) as c:
+        monkeypatch.delenv("QCDGPU_AMD_GH")
+        assert c.pass_uses_pair_kernel()
+        c.init_lattice()
+        c.sweep(1)
+        lat.sweep(1)
+        p0 = c.plaquette()
+        c.overrelax_sweep(2)
+        lat.overrelax_sweep(2)
+        assert abs(c.plaquette()[2] - p0[2]) < 1e-13
+        assert np.max(np.abs(c.download() - lat.export_table())) < 1e-10
+        c.sweep(1)                                         # the generator was left alone
+        lat.sweep(1)
+        assert c.rng_draws() == ol.rng_draws(lat)
+        assert _rel(c.plaquette(), lat.plaquette()) < REL
+    lat.close()
+
+
+def test_overrelaxation_32x4_both_kernels_agree(monkeypatch):
+    """At the benchmark's 32^4 the pass runs as the pair kernel by itself: same links as the one-wavefront-per-block
+    kernel (chosen by switching the pair kernel off for a second context), action unchanged, every link moved."""
+    L = (32, 32, 32, 32)
+    with _ctx(group=3, L=L, beta=6.0, nhit=10) as a:
+        assert a.pass_uses_pair_kernel()
+        a.init_lattice()
+        a.sweep(2)
+        start = a.download()
+        monkeypatch.setenv("QCDGPU_AMD_GH", "0")
+        with _ctx(group=3, L=L, beta=6.0, nhit=10) as b:
+            monkeypatch.delenv("QCDGPU_AMD_GH")
+            assert not b.pass_uses_pair_kernel()
+            b.upload(start)
+            p0 = a.plaquette()
+            a.overrelax_sweep(1)
+            b.overrelax_sweep(1)
+            got = a.download()
+            assert np.max(np.abs(got - b.download())) < 1e-13
+            assert abs(a.plaquette()[2] - p0[2]) < 1e-13
+            assert np.mean(np.abs(got - start)) > 1e-2
+
+
 @pytest.mark.parametrize("group,L,beta", [(3, (6, 4, 8, 6), 6.0), (2, (4, 8, 6, 6), 2.4), (3, (5, 4, 6, 7), 6.0)])
 def test_wilson_loop_matches_checker(group, L, beta):
     import qcdgpu_amd as q
