@@ -405,6 +405,25 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     if world == 1:
+        # the other half of the link update the workload names: overrelaxation sweeps on the thermalised configuration,
+        # device time per pass from the library's own event bracket (not part of `value`; same algorithmic bytes)
+        try:
+            ctx.overrelax_sweep(2)
+            ctx.set_profiling(True)
+            t0 = ctx.timing()
+            ctx.overrelax_sweep(10)
+            t1 = ctx.timing()
+            ctx.set_profiling(False)
+            o_pass_s = 1e-3 * (t1.update_ms - t0.update_ms) / (t1.update_launches - t0.update_launches)
+            o_gbs = bytes_per_launch / o_pass_s / 1e9
+            result.setdefault("other_workloads", {})["su3_%dx4_overrelaxation" % n] = {
+                "link_updates_per_s": (sites_per_gpu / 2) / o_pass_s, "ms_per_sweep": 8e3 * o_pass_s,
+                "workload": "SU(3) %d^4 overrelaxation sweep (microcanonical reflection in the three SU(2) subgroups, re-unitarised), fp64" % n,
+                "roofline": {"bound": "hbm", "achieved": o_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": o_gbs / HBM_PEAK_GBS,
+                             "kernel": "k_update_gh<.., OVR>" if ctx.pass_uses_pair_kernel() else "k_overrelax",
+                             "avg_launch_us": 1e6 * o_pass_s, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None}}
+        except q.QcdError as e:
+            log("overrelaxation leg skipped: %s" % e)
         # the chain's mean plaquette beside the mean of the reference program's own chain at this size (a committed fixture:
         # different random streams, the same Markov kernel and start), outside the timed region
         chain = reference_chain(L, args.beta)
@@ -445,14 +464,14 @@ def main():
                 on_pass_s = on_ms * 1e-3 / 40
                 on_bytes = 40.0 * 64.0 ** 4 / 2
                 on_gbs = on_bytes / on_pass_s / 1e9
-                result["other_workloads"] = {"on_sigma_64x4_f32": {
+                result.setdefault("other_workloads", {})["on_sigma_64x4_f32"] = {
                     "site_updates_per_s": 64.0 ** 4 * 20 / (on_ms * 1e-3), "ms_per_sweep": on_ms / 20,
                     "workload": "O(N) scalar model 64^4, single precision, NHIT=10, RANLUX3, cold start, 20 sweeps",
                     "roofline": {"bound": "hbm", "achieved": on_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": on_gbs / HBM_PEAK_GBS, "kernel": "k_on_update<float>",
                                  "avg_launch_us": 1e6 * on_pass_s, "algorithmic_bytes_per_launch": on_bytes,
                                  "traffic": measured_traffic("on_hbm_bytes_per_update_launch"),
-                                 "limited_by": measured_traffic("on_limited_by")}}}
+                                 "limited_by": measured_traffic("on_limited_by")}}
         except q.QcdError as e:
             log("O(N) leg skipped: %s" % e)
         # the headline lattice in single precision (the reference's PRECISION switch; its paper quotes every
