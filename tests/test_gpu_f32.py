@@ -220,6 +220,15 @@ def test_su3_32_pair_kernel_path():
             _check(c.wilson_loop(2, 3), d.wilson_loop(2, 3))
             for field in (0, 1):
                 _check(c.fmunu(field, 3, 8), d.fmunu(field, 3, 8), rel=2e-4)
+            # the overrelaxation pass of this size runs through the same wavefront pairs: one sweep in both precisions
+            # from the same links (reflections have no accept step, so float and double stay within rounding)
+            before = c.plaquette()[2]
+            c.overrelax_sweep(1)
+            d.overrelax_sweep(1)
+            assert abs(c.plaquette()[2] - before) < 2e-6 * before
+            moved = c.download()
+            assert np.max(np.abs(moved - d.download())) < 2e-5
+            assert np.mean(np.abs(moved - t)) > 1e-2
 
 
 def test_hot_start_and_state_round_trip():
