@@ -330,6 +330,11 @@ int qcd_prng_check(int device, unsigned rand_series, int lux_level, int streams,
  * x = k * 2^-24 in (0, 1), against the host libm in long double */
 int qcd_math_check(int device, int n, double max_ulp[4]);
 
+/* the same for the accept step's fp64 cos(2 pi r) and sin(2 pi r) (a 256-entry table of angles plus a Taylor series for
+ * the rest; the reference calls the OpenCL built-ins on the rounded product 2 pi r): worst ABSOLUTE error of the cosine
+ * and of the sine over n arguments r of the forms the generator delivers, against the host libm in long double */
+int qcd_trig_check(int device, int n, double max_abs_err[2]);
+
 /* ---------------------------------------------------------------------------------------------
  * O(N) scalar path: the reference's second model (its O(N) tree, MODEL_ON = 1), one real field
  * value per site, checkerboard multi-hit Metropolis.  Same boundary as above: each entry point

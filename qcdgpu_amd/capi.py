@@ -52,7 +52,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_precision", "qcd_
            "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_update_signal_edges", "qcd_halo_region", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
            "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
-           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check",
+           "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check", "qcd_trig_check",
            "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range",
            "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
            "qcd_on_create", "qcd_on_destroy", "qcd_on_init_lattice", "qcd_on_update", "qcd_on_sweep",
@@ -128,6 +128,7 @@ def _load(path=None):
     lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
     lib.qcd_prng_check.argtypes = [I, C.c_uint, I, I, I, C.POINTER(C.c_uint)]
     lib.qcd_math_check.argtypes = [I, I, C.POINTER(C.c_double)]
+    lib.qcd_trig_check.argtypes = [I, I, C.POINTER(C.c_double)]
     lib.qcd_overrelax.argtypes = [P, I, I]
     lib.qcd_update_range.argtypes = [P, I, I, I, I]
     lib.qcd_update_split.argtypes = [P, I, I, I, I]
@@ -447,6 +448,13 @@ def math_check(device=0, n=1 << 20):
     """Worst error (ulp) of the engine's own log(1-x), sqrt, 1/x, 1/sqrt against the host libm."""
     out = (C.c_double * 4)()
     _check(lib.qcd_math_check(device, n, out))
+    return np.array(out[:])
+
+
+def trig_check(device=0, n=1 << 20):
+    """Worst absolute error of the engine's own fp64 cos(2 pi r), sin(2 pi r) against the host libm in long double."""
+    out = (C.c_double * 2)()
+    _check(lib.qcd_trig_check(device, n, out))
     return np.array(out[:])
 
 

@@ -1689,6 +1689,59 @@ int qcd_math_check(int device, int n, double max_ulp[4])
     return QCD_OK;
 }
 
+// Self-check of the accept step's fp64 cosine and sine of 2 pi r (MathFast::sincos_2pi: table + Taylor series) against
+// the host libm in long double: n arguments r in [0, 1) of the forms the generator delivers -- k 2^-24, and below 2^-12
+// with the bits of its correction term behind them; worst absolute errors.
+int qcd_trig_check(int device, int n, double max_abs_err[2])
+{
+    if (!max_abs_err || n < 1) return fail(QCD_ERR_INVALID, "bad arguments");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(QCD_ERR_INVALID, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<float> in((size_t)n);
+    std::vector<double> out((size_t)2 * n);
+    unsigned long long lcg = 88172645463325252ull;
+    for (int i = 0; i < n; i++) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        unsigned k = (unsigned)(lcg >> 40);                 // 24 bits
+        float r = (float)k * 5.9604644775390625e-8f;
+        if (i % 5 == 0) {
+            // a value below 2^-12 with the correction term (ranlux.h, rlx_batch)
+            k &= 4095u;
+            const unsigned sj = (unsigned)(lcg >> 16) & 0xFFFFFFu;
+            r = (float)k * 5.9604644775390625e-8f;
+            r = r + 5.9604644775390625e-8f * ((float)sj * 5.9604644775390625e-8f);
+        }
+        if (i % 9 == 0) r = (float)((k & 0xFF0000u) | (i % 18 == 0 ? 0x7FFFu : 0x8000u)) * 5.9604644775390625e-8f;   // either side of the table's midpoints
+        if (i < 256) r = (float)((unsigned)i << 16) * 5.9604644775390625e-8f;   // the table's own angles
+        in[(size_t)i] = r;
+    }
+    float* d_in = nullptr;
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, in.size() * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, out.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_in, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_trig_check<MEAS_BLOCK>), dim3(cdiv((long)n, MEAS_BLOCK)), dim3(MEAS_BLOCK), 0, 0, d_in, n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(QCD_ERR_HIP, "trig check: %s", hipGetErrorString(e));
+    max_abs_err[0] = max_abs_err[1] = 0.0;
+    const long double two_pi = 2.0L * acosl(-1.0L);
+    for (int i = 0; i < n; i++) {
+        const long double a = two_pi * (long double)in[(size_t)i];
+        const double ec = (double)fabsl((long double)out[(size_t)i] - cosl(a));
+        const double es = (double)fabsl((long double)out[(size_t)n + i] - sinl(a));
+        if (ec > max_abs_err[0]) max_abs_err[0] = ec;
+        if (es > max_abs_err[1]) max_abs_err[1] = es;
+    }
+    return QCD_OK;
+}
+
 // n values of stream `stream` produced by the batch formulation the kernels use
 int qcd_host_ranlux_stream(unsigned rand_series, int stream, int lux_level, int n, float* out)
 {

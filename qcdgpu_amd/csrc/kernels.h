@@ -506,7 +506,7 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, real beta, real be
                                      4.0e-6f * fabsf(d32) + 4.0e-6f;
                 bool acc = t32 > margin;
                 if (fabsf(t32) <= margin) {
-                    const double cosrnd = cos_2pi(rnd[1]);
+                    const double cosrnd = m.cos_2pi(rnd[1], double());
                     const double d = -(m.log_of(1.0 - rnd[0]) + cosrnd * cosrnd * m.log_of(1.0 - rnd[2])) * ibdet;
                     acc = (r3sq <= (1.0 - 0.5 * d));
                 }
@@ -519,7 +519,7 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, real beta, real be
                 i++;
             }
             if (flag) {
-                const double cosrnd = cos_2pi(a1);
+                const double cosrnd = m.cos_2pi(a1, double());
                 delta = -(m.log_of(1.0 - a0) + cosrnd * cosrnd * m.log_of(1.0 - a2)) * ibdet;
             }
         } else {
@@ -528,7 +528,7 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, real beta, real be
             int i = 0;
             while ((i < nhit) && !flag) {
                 rng.draw4(rnd);
-                const float cosrnd = cos_2pi(rnd[1]);
+                const float cosrnd = m.cos_2pi(rnd[1], float());
                 const float d = -(m.log_of(1.0f - rnd[0]) + cosrnd * cosrnd * m.log_of(1.0f - rnd[2])) * ibdet;
                 if (rnd[3] * rnd[3] <= (1.0f - 0.5f * d)) {
                     flag = true;
@@ -545,7 +545,7 @@ __device__ __forceinline__ bool heatbath_su2(const su2& stap, real beta, real be
         const real sinth = m.sqrt_of((real)1 - costh * costh);
         const real sinal = m.sqrt_of((real)1 - cosal * cosal);
         real sinphi, cosphi;
-        sincos_2pi(rnd[1], sinphi, cosphi);
+        m.sincos_2pi(rnd[1], sinphi, cosphi);
         su2 c;
         c.e[0][0] = mk(cosal, sinal * costh);
         c.e[0][1] = mk(sinal * sinth * sinphi, sinal * sinth * cosphi);
@@ -1125,10 +1125,13 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass needs the signature only
     __shared__ float rbuf[GID ? 1 : RLX_ROWS * BLOCK];
     __shared__ double2 logtab[LOG_TABLE_ENTRIES];
+    __shared__ double2 trigtab[REAL_IS_DOUBLE ? TRIG_TABLE_ENTRIES : 1];   // the fp64 accept step's cosine and sine (MathFast::sincos_2pi)
     MathFast::fill<BLOCK>(logtab);
+    if constexpr (REAL_IS_DOUBLE) MathFast::fill_trig<BLOCK>(trigtab);
     __syncthreads();
     MathFast fm;
     fm.tab = logtab;
+    fm.trig = trigtab;
     unsigned long long used = 0;
     (void)args_by_value;
     typedef const UpdArgs __attribute__((address_space(4))) * ArgPtr;
@@ -1324,6 +1327,7 @@ struct GhShared {
     real2 stap[TEAMS][GH_SLOTS][PER][9][64];              // partial staple sums: 18 reals per lane
     float rbuf[GH_SIDE][RLX_ROWS_KEEP * 64];         // random numbers of the heat-bath wavefronts, and a kept generator state
     double2 logtab[LOG_TABLE_ENTRIES];
+    double2 trigtab[REAL_IS_DOUBLE ? TRIG_TABLE_ENTRIES : 1];   // the fp64 accept step's cosine and sine (MathFast::sincos_2pi)
     unsigned full_seq[TEAMS][GH_SLOTS][PER];                // gather wavefront j has put block (full_seq - 1) into the slot
     unsigned free_seq[TEAMS][GH_SLOTS];                     // the heat-bath side has read block (free_seq - 1) out of the slot
     unsigned simd_count[4];
@@ -1469,6 +1473,7 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
     if (threadIdx.x < TEAMS * GH_SLOTS * PER) (&sh.full_seq[0][0][0])[threadIdx.x] = 0u;
     if (threadIdx.x < TEAMS * GH_SLOTS) (&sh.free_seq[0][0])[threadIdx.x] = 0u;
     if constexpr (!OVR) MathFast::fill<512>(sh.logtab);   // the reflection takes no logarithm
+    if constexpr (!OVR && REAL_IS_DOUBLE) MathFast::fill_trig<512>(sh.trigtab);
     __syncthreads();
     const unsigned simd = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11))) & 3u;   // HW_ID bits 5:4
     unsigned role = 0;
@@ -1501,6 +1506,7 @@ __global__ __launch_bounds__(512, 2) void k_update_gh(const UpdArgs a)
         const int parity = a.parity;
         MathFast fm;
         fm.tab = sh.logtab;
+        fm.trig = sh.trigtab;
         unsigned long long used = 0;
         QCD_GH_SPIN_DECL;
         float* rcol = &sh.rbuf[member][lane];
@@ -2570,6 +2576,24 @@ __global__ __launch_bounds__(BLOCK) void k_math_check(const double* __restrict__
     double s, is;
     fm.sqrt_rcp(x + 1e-3, s, is);
     out[3 * n + i] = is;
+}
+
+// self-check of MathFast::sincos_2pi: in[i] (a float) -> out[i] = cos(2 pi in[i]), out[n + i] = sin(2 pi in[i])
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trig_check(const float* __restrict__ in, const int n, double* __restrict__ out)
+{
+    __shared__ double2 trigtab[TRIG_TABLE_ENTRIES];
+    MathFast::fill_trig<BLOCK>(trigtab);
+    __syncthreads();
+    MathFast fm;
+    fm.tab = nullptr;
+    fm.trig = trigtab;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    fm.sincos_2pi(in[i], s, c);
+    out[i] = c;
+    out[n + i] = s;
 }
 
 // ---------------------------------------------------------------------------------------------

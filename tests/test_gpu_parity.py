@@ -260,6 +260,15 @@ def test_heatbath_math_is_accurate_to_the_last_places():
     assert log_ulp <= 2.0 and sqrt_ulp <= 1.0 and rcp_ulp <= 1.5 and rsqrt_ulp <= 2.5, (log_ulp, sqrt_ulp, rcp_ulp, rsqrt_ulp)
 
 
+def test_accept_step_cosine_and_sine_are_accurate():
+    """cos(2 pi r), sin(2 pi r) of the fp64 accept step (table of 256 angles + Taylor series) against the host libm in
+    long double, on RANLUX-shaped arguments including those below 2^-12 with their correction bits: within 1.5e-16 of
+    the exact value (the reference's own cos(PI2 * r) is 6e-16 from it: the product is rounded first)."""
+    import qcdgpu_amd as q
+    err_cos, err_sin = q.trig_check(device=0, n=1 << 21)
+    assert err_cos <= 1.5e-16 and err_sin <= 1.5e-16, (err_cos, err_sin)
+
+
 @pytest.mark.parametrize("group,L", [(3, (2, 2, 2, 2)), (3, (2, 6, 2, 2)), (3, (6, 10, 2, 4)), (3, (4, 34, 4, 4)),
                                      (2, (2, 2, 2, 2)), (2, (10, 6, 6, 2)), (3, (3, 2, 3, 3)), (2, (3, 2, 5, 3)), (3, (7, 18, 4, 5))])
 def test_small_and_ragged_lattices(group, L):
