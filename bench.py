@@ -406,22 +406,19 @@ def main():
     }
     if world == 1:
         # the other half of the link update the workload names: overrelaxation sweeps on the thermalised configuration,
-        # device time per pass from the library's own event bracket (not part of `value`; same algorithmic bytes)
+        # device time per pass from a HIP-event bracket like the headline's (not part of `value`; same algorithmic bytes)
         try:
             ctx.overrelax_sweep(2)
-            ctx.set_profiling(True)
-            t0 = ctx.timing()
-            ctx.overrelax_sweep(10)
-            t1 = ctx.timing()
-            ctx.set_profiling(False)
-            o_pass_s = 1e-3 * (t1.update_ms - t0.update_ms) / (t1.update_launches - t0.update_launches)
+            o_ms, o_launches = ctx.timed_overrelax_sweeps(10)
+            o_pass_s = 1e-3 * o_ms / o_launches
             o_gbs = bytes_per_launch / o_pass_s / 1e9
             result.setdefault("other_workloads", {})["su3_%dx4_overrelaxation" % n] = {
                 "link_updates_per_s": (sites_per_gpu / 2) / o_pass_s, "ms_per_sweep": 8e3 * o_pass_s,
                 "workload": "SU(3) %d^4 overrelaxation sweep (microcanonical reflection in the three SU(2) subgroups, re-unitarised), fp64" % n,
                 "roofline": {"bound": "hbm", "achieved": o_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": o_gbs / HBM_PEAK_GBS,
                              "kernel": "k_update_gh<.., OVR>" if ctx.pass_uses_pair_kernel() else "k_overrelax",
-                             "avg_launch_us": 1e6 * o_pass_s, "algorithmic_bytes_per_launch": bytes_per_launch, "traffic": None}}
+                             "avg_launch_us": 1e6 * o_pass_s, "algorithmic_bytes_per_launch": bytes_per_launch,
+                             "traffic": measured_traffic("overrelaxation_hbm_bytes_per_launch") if (n == 32 and args.beta == 6.0) else None}}
         except q.QcdError as e:
             log("overrelaxation leg skipped: %s" % e)
         # the chain's mean plaquette beside the mean of the reference program's own chain at this size (a committed fixture:

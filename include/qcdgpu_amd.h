@@ -314,6 +314,8 @@ int qcd_get_timing(qcd_ctx *ctx, qcd_timing *out);
 /* runs n sweeps bracketed by HIP events on the context's stream; returns the elapsed device
  * time of the whole bracket in ms and the number of update launches inside it */
 int qcd_timed_sweeps(qcd_ctx *ctx, int n, double *elapsed_ms, unsigned long long *launches);
+/* the same for n overrelaxation sweeps (qcd_overrelax_sweep) */
+int qcd_timed_overrelax_sweeps(qcd_ctx *ctx, int n, double *elapsed_ms, unsigned long long *launches);
 
 /* number of random numbers consumed so far by all RANLUX streams of this context */
 int qcd_rng_draws(qcd_ctx *ctx, unsigned long long *draws);

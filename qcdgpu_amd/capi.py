@@ -51,7 +51,7 @@ EXPORTS = ["qcd_create", "qcd_destroy", "qcd_last_error", "qcd_precision", "qcd_
            "qcd_measure_plaquette_sums", "qcd_measure_polyakov_sums", "qcd_upload", "qcd_download",
            "qcd_halo_bytes", "qcd_halo_pack", "qcd_halo_unpack", "qcd_update_signal_edges", "qcd_halo_region", "qcd_halo_copy",
            "qcd_device_count", "qcd_device_name", "qcd_set_profiling",
-           "qcd_get_timing", "qcd_timed_sweeps", "qcd_rng_draws", "qcd_prng_check",
+           "qcd_get_timing", "qcd_timed_sweeps", "qcd_timed_overrelax_sweeps", "qcd_rng_draws", "qcd_prng_check",
            "qcd_rng_state_bytes", "qcd_rng_state_download", "qcd_rng_state_upload", "qcd_math_check", "qcd_trig_check",
            "qcd_overrelax", "qcd_overrelax_sweep", "qcd_measure_wilson", "qcd_update_range",
            "qcd_update_split", "qcd_measure_fmunu", "qcd_measure_fmunu_sums", "qcd_measure_plaquette_profile_sums", "qcd_measure_polyakov_profile_sums",
@@ -123,6 +123,7 @@ def _load(path=None):
     lib.qcd_set_profiling.argtypes = [P, I]
     lib.qcd_get_timing.argtypes = [P, C.POINTER(Timing)]
     lib.qcd_timed_sweeps.argtypes = [P, I, pd, C.POINTER(C.c_ulonglong)]
+    lib.qcd_timed_overrelax_sweeps.argtypes = [P, I, pd, C.POINTER(C.c_ulonglong)]
     lib.qcd_rng_draws.argtypes = [P, C.POINTER(C.c_ulonglong)]
     # host-only helpers (no device needed)
     lib.qcd_host_ranlux_stream.argtypes = [C.c_uint, I, I, I, C.POINTER(C.c_float)]
@@ -318,6 +319,12 @@ class Context:
         ms = C.c_double()
         launches = C.c_ulonglong()
         self._check(self.lib.qcd_timed_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
+        return ms.value, launches.value
+
+    def timed_overrelax_sweeps(self, n):
+        ms = C.c_double()
+        launches = C.c_ulonglong()
+        self._check(self.lib.qcd_timed_overrelax_sweeps(self.h, n, C.byref(ms), C.byref(launches)))
         return ms.value, launches.value
 
     def update_range(self, parity, direction, xs_begin, xs_count):

@@ -1541,7 +1541,19 @@ int qcd_get_timing(qcd_ctx* c, qcd_timing* out)
     return QCD_OK;
 }
 
+namespace {
+int timed_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* launches, bool overrelax);
+}
 int qcd_timed_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* launches)
+{
+    return timed_sweeps(c, n, elapsed_ms, launches, false);
+}
+int qcd_timed_overrelax_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* launches)
+{
+    return timed_sweeps(c, n, elapsed_ms, launches, true);
+}
+namespace {
+int timed_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* launches, bool overrelax)
 {
     int rc = check_ctx(c, true);
     if (rc) return rc;
@@ -1552,7 +1564,7 @@ int qcd_timed_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* 
     HIP_TRY(hipEventCreate(&b));
     const unsigned long long before = c->timing.update_launches;
     HIP_TRY(hipEventRecord(a, c->stream));
-    rc = qcd_sweep(c, n);
+    rc = overrelax ? qcd_overrelax_sweep(c, n) : qcd_sweep(c, n);
     hipError_t e = hipEventRecord(b, c->stream);
     if (e == hipSuccess) e = hipEventSynchronize(b);
     float ms = 0.f;
@@ -1565,6 +1577,7 @@ int qcd_timed_sweeps(qcd_ctx* c, int n, double* elapsed_ms, unsigned long long* 
     if (launches) *launches = c->timing.update_launches - before;
     return QCD_OK;
 }
+}  // namespace
 
 int qcd_rng_draws(qcd_ctx* c, unsigned long long* draws)
 {
