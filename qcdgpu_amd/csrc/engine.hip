@@ -670,6 +670,11 @@ int qcd_create(qcd_ctx** out, const qcd_params* p)
     g.rz = g.nz / g.nzr;
     g.rt = g.tq / g.ntr;
     g.region_h = g.nyh * g.rz * g.rt;   // half-sites of a region per x slice and group member
+    {
+        auto log2_of = [](int v) { int l = 0; while ((1 << l) < v) l++; return ((1 << l) == v) ? l : -1; };
+        const int lr = log2_of(g.region_h), lp = log2_of(g.nyh * g.rz), ly = log2_of(g.nyh);
+        g.idx_shifts = (lr >= 0 && lp >= 0 && ly >= 0 && !getenv("QCDGPU_AMD_NO_SHIFTS")) ? ((lr << 16) | (lp << 8) | ly) : -1;   // diagnostic switch: always divide
+    }
     g.tz = g.tt = g.tx = 0;
     g.ux0 = 0;
     g.unx = g.nx;

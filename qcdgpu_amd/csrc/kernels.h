@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(BLOCK, QCD_UPD_WAVES) void k_update(const UpdArgs a
     g.nx = ap->g.nx; g.ny = ap->g.ny; g.nz = ap->g.nz; g.nt = ap->g.nt;
     g.halo = ap->g.halo; g.x0 = ap->g.x0; g.nyh = ap->g.nyh; g.slice_h = ap->g.slice_h;
     g.vh_int = ap->g.vh_int; g.vh_alloc = ap->g.vh_alloc; g.gsites = ap->g.gsites; g.gslice = ap->g.gslice;
-    g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h;
+    g.nzr = ap->g.nzr; g.ntr = ap->g.ntr; g.rz = ap->g.rz; g.rt = ap->g.rt; g.region_h = ap->g.region_h; g.idx_shifts = ap->g.idx_shifts;
     g.tz = ap->g.tz; g.tt = ap->g.tt; g.tx = ap->g.tx;
     g.ux0 = ap->g.ux0; g.unx = ap->g.unx; g.odd = ap->g.odd; g.share = ap->g.share; g.tq = ap->g.tq;
     const int wb = ((wg / (g.nzr * g.ntr)) * g.share + sub) * (g.nzr * g.ntr) + wg % (g.nzr * g.ntr);

@@ -46,6 +46,9 @@ struct Geom {
     int nzr, ntr;        // regions along z and t
     int rz, rt;          // z and t extent of a region
     int region_h;        // half-sites of a region per x slice = nyh*rz*rt
+    // when region_h, nyh*rz and nyh are all powers of two: their logarithms in bits 16.., 8..15, 0..7, so that a lane
+    // finds its site with shifts; -1: by divisions (three per site and wavefront: 5 % of a 32^4 pass's instructions)
+    int idx_shifts;
     // shape of the block of sites one workgroup updates inside its region: all of y times
     // tz x tt x tx sites in z, t, x (tz = 0: a run of consecutive half-sites, y then z then t)
     int tz, tt, tx;
@@ -140,13 +143,23 @@ __device__ __forceinline__ bool site_of_workgroup(const Geom& g, int b, int tid,
         sub = T - grp * g.share;
         const int w = grp * BLOCK + tid;
         if (w >= g.unx * g.region_h) return false;
-        s.xs = w / g.region_h;
-        int q = w - s.xs * g.region_h;
-        const int plane = g.nyh * g.rz;
-        tl = q / plane;
-        q -= tl * plane;
-        zl = q / g.nyh;
-        yh = q - zl * g.nyh;
+        if (g.idx_shifts >= 0) {   // wave-uniform
+            const int sr = g.idx_shifts >> 16, sp = (g.idx_shifts >> 8) & 255, sy = g.idx_shifts & 255;
+            s.xs = w >> sr;
+            int q = w & ((1 << sr) - 1);
+            tl = q >> sp;
+            q &= (1 << sp) - 1;
+            zl = q >> sy;
+            yh = q & ((1 << sy) - 1);
+        } else {
+            s.xs = w / g.region_h;
+            int q = w - s.xs * g.region_h;
+            const int plane = g.nyh * g.rz;
+            tl = q / plane;
+            q -= tl * plane;
+            zl = q / g.nyh;
+            yh = q - zl * g.nyh;
+        }
     }
     s.xs += g.ux0;   // position inside the launch's slice range -> owned slice, wrapping
     if (s.xs >= g.nx) s.xs -= g.nx;
