@@ -242,6 +242,11 @@ int qcd_on_create(qcd_on_ctx** out, const qcd_on_params* p)
     g.nyh = g.ny / 2;
     g.slice_h = g.nyh * g.nz * g.nt;
     g.vh = g.nx * g.slice_h;
+    {
+        auto log2_of = [](int v) { int l = 0; while ((1 << l) < v) l++; return ((1 << l) == v) ? l : -1; };
+        const int ly = log2_of(g.nyh), lz = log2_of(g.nz), lt = log2_of(g.nt);
+        g.idx_shifts = (ly >= 0 && lz >= 0 && lt >= 0) ? ((lt << 16) | (lz << 8) | ly) : -1;
+    }
     // model::model_lattice_init, O(N)/suncl/suncl.cpp:1244-1253
     c->sqrt_z_lambda_zeta = 0.25 * sqrt(p->z / (p->lambda * p->zeta));
     if (p->eta > 0.0) {

@@ -33,6 +33,7 @@ struct OnGeom {
     int nyh;       // ny / 2
     int slice_h;   // half-sites per x slice
     int vh;        // half-sites of the lattice = threads of an update pass
+    int idx_shifts;   // nyh, nz and nt all powers of two: their logarithms in bits 0..7, 8..15, 16..; else -1 (divisions)
 };
 
 // lattice_parameters[16..22] (O(N)/suncl/suncl.cpp:1987-1994) and SKGROUP
@@ -49,12 +50,23 @@ struct OnSite {
 __device__ __forceinline__ OnSite on_site_of(const OnGeom& g, int h, int par)
 {
     OnSite s;
-    const int yh = h % g.nyh;
-    int r = h / g.nyh;
-    s.z = r % g.nz;
-    r /= g.nz;
-    s.t = r % g.nt;
-    s.x = r / g.nt;
+    int yh;
+    if (g.idx_shifts >= 0) {   // uniform over the launch
+        const int sy = g.idx_shifts & 255, sz = (g.idx_shifts >> 8) & 255, st = g.idx_shifts >> 16;
+        yh = h & ((1 << sy) - 1);
+        int r = h >> sy;
+        s.z = r & ((1 << sz) - 1);
+        r >>= sz;
+        s.t = r & ((1 << st) - 1);
+        s.x = r >> st;
+    } else {
+        yh = h % g.nyh;
+        int r = h / g.nyh;
+        s.z = r % g.nz;
+        r /= g.nz;
+        s.t = r % g.nt;
+        s.x = r / g.nt;
+    }
     s.y = 2 * yh + ((par + s.x + s.z + s.t) & 1);
     return s;
 }
