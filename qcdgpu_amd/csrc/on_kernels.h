@@ -85,7 +85,15 @@ __device__ __forceinline__ void on_forward(const OnGeom& g, const OnSite& s, int
     nb[3] = (s.t == g.nt - 1) ? h - (g.nt - 1) * g.nyh * g.nz : h + g.nyh * g.nz;
 }
 
+// single precision: the hardware's base-2 logarithm (1 ulp) times ln 2 -- the reference's device code calls OpenCL's
+// log on a float, which the standard lets be 3 ulp off; the library routine costs twelve times the instructions and the
+// action takes four of these per proposal.  A stored field value is the proposal itself, so the last place of a
+// logarithm only matters to a proposal that close to its threshold (about one in 1e6).
+#ifdef QCD_ON_LIB_LOGF   // diagnostic build: the library logarithm, as before round 3
 __device__ __forceinline__ float on_log(float x) { return logf(x); }
+#else
+__device__ __forceinline__ float on_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+#endif
 __device__ __forceinline__ double on_log(double x) { return log(x); }
 __device__ __forceinline__ float on_exp(float x) { return expf(x); }
 __device__ __forceinline__ double on_exp(double x) { return exp(x); }
