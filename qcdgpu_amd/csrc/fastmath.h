@@ -141,8 +141,19 @@ struct MathFast {
         sincos_2pi(r, s, c);
         return c;
     }
+    // single precision: the hardware's cosine and sine take their argument in revolutions (1.3e-7 absolute over all
+    // 2^24 arguments, tools/fp32_bounds.hip)
+#ifdef QCD_LIB_TRIG
     __device__ __forceinline__ float cos_2pi(float r, float) const { return cospif(2.0f * r); }
     __device__ __forceinline__ void sincos_2pi(float r, float& s, float& c) const { sincospif(2.0f * r, &s, &c); }
+#else
+    __device__ __forceinline__ float cos_2pi(float r, float) const { return __builtin_amdgcn_cosf(r); }
+    __device__ __forceinline__ void sincos_2pi(float r, float& s, float& c) const
+    {
+        s = __builtin_amdgcn_sinf(r);
+        c = __builtin_amdgcn_cosf(r);
+    }
+#endif
 
     // one thread per entry fills the table (call with every thread of the block, then barrier)
     template <int BLOCK>
